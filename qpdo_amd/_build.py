@@ -1,0 +1,93 @@
+"""In-tree builds of the native libraries (no JIT cache: the .so files travel with the tree).
+
+  libqpdo_amd.so  -- the product: C host driver + HIP kernels for gfx950 (hipcc)
+  libqpdo_gen.so  -- synthetic problem generator (gcc, OpenMP); workload synthesis only
+"""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+LIB_PATH = os.path.join(_HERE, "libqpdo_amd.so")
+GEN_PATH = os.path.join(_HERE, "libqpdo_gen.so")
+
+HIP_SOURCES = ["qpdo_dev.hip"]
+C_SOURCES = ["qpdo_api.c"]
+HEADERS = ["qpdo_dev.h", os.path.join(INCLUDE, "qpdo.h"), os.path.join(INCLUDE, "qpdo_amd_ext.h")]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    for s in sources:
+        s = s if os.path.isabs(s) else os.path.join(CSRC, s)
+        if os.path.exists(s) and os.path.getmtime(s) > t:
+            return True
+    return False
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def build_gen(force=False):
+    src = os.path.join(CSRC, "qpdo_gen.c")
+    if force or _stale(GEN_PATH, [src]):
+        subprocess.check_call(["gcc", "-O3", "-std=gnu11", "-fPIC", "-fopenmp", "-shared",
+                               "-o", GEN_PATH, src, "-lm"])
+    return GEN_PATH
+
+
+def ensure_gen():
+    if os.path.exists(GEN_PATH) and not _stale(GEN_PATH, [os.path.join(CSRC, "qpdo_gen.c")]):
+        return GEN_PATH
+    return build_gen()
+
+
+def build_lib(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 for the kernels, plain C for the host driver."""
+    if not (force or _stale(LIB_PATH, HIP_SOURCES + C_SOURCES + HEADERS)):
+        return LIB_PATH
+    cc = hipcc()
+    if cc is None:
+        raise RuntimeError("hipcc not found: libqpdo_amd.so cannot be built")
+    objs = []
+    common = ["-O3", "-fPIC", "-I", INCLUDE, "-I", CSRC]
+    for s in HIP_SOURCES:
+        o = os.path.join(CSRC, s + ".o")
+        cmd = [cc, "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
+               *common, "-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        subprocess.check_call(cmd)
+        objs.append(o)
+    for s in C_SOURCES:
+        o = os.path.join(CSRC, s + ".o")
+        subprocess.check_call(["gcc", "-std=gnu11", "-ffp-contract=off", "-Wall", *common,
+                               "-c", os.path.join(CSRC, s), "-o", o])
+        objs.append(o)
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-lm"])
+    return LIB_PATH
+
+
+def ensure_lib():
+    """Path of the product library; builds it when the sources are newer.  Never falls back
+    to anything else: a missing library is an error."""
+    if os.path.exists(LIB_PATH) and not _stale(LIB_PATH, HIP_SOURCES + C_SOURCES + HEADERS):
+        return LIB_PATH
+    if hipcc() is None:
+        if os.path.exists(LIB_PATH):
+            return LIB_PATH
+        raise RuntimeError("libqpdo_amd.so is missing and hipcc is unavailable; "
+                           "run __graft_entry__.build() where ROCm is installed")
+    return build_lib()
+
+
+def build_all(force=False, verbose=False):
+    return build_gen(force), build_lib(force, verbose)

@@ -1,0 +1,108 @@
+"""Synthetic QP instances for tests and bench.py.
+
+`random_qp` wraps the seeded C generator (csrc/qpdo_gen.c).  `infeasibility_kat`
+returns the three explicit 2-variable QPs of the reference's
+examples/infeasibility_tests.m:15-68 (data only), with MATLAB's conventions
+applied by hand: sparse() drops explicit zeros and the qpdo.m front end clips
+infinite bounds to +-1e20 (interfaces/mex/qpdo.m:138-139).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _build
+
+QPDO_INFTY = 1e20
+
+# (name, shape, density, n_eq, seed offset): BASELINE.json configs / SURVEY.md section 8
+CONFIGS = {
+    "C1": dict(n=200, m=100, density=0.1, n_eq=0),       # examples/demo_mex.m:7-9
+    "C1b": dict(n=50, m=100, density=0.1, n_eq=0),       # BASELINE.json configs[0] shape
+    "C2": dict(n=10_000, m=20_000, density=0.01, n_eq=0),
+    "C3": dict(n=120, m=360, density=0.1, n_eq=120),
+    "C4": dict(n=100_000, m=200_000, density=0.01, n_eq=0),
+}
+BASE_SEED = 123456  # examples/demo_mex.m:4
+
+_gen = None
+
+
+def _genlib():
+    global _gen
+    if _gen is None:
+        L = C.CDLL(_build.ensure_gen())
+        ip, dp = C.POINTER(C.c_int64), C.POINTER(C.c_double)
+        L.qpdo_gen_A_per_col.restype = C.c_int64
+        L.qpdo_gen_A_per_col.argtypes = [C.c_int64, C.c_double]
+        L.qpdo_gen_Q_nnz.restype = C.c_int64
+        L.qpdo_gen_Q_nnz.argtypes = [C.c_int64, C.c_double]
+        L.qpdo_gen_problem.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_double, C.c_int64,
+                                       ip, ip, dp, ip, ip, dp, dp, dp, dp]
+        _gen = L
+    return _gen
+
+
+def random_qp(seed, n, m, density, n_eq=0):
+    """Seeded random sparse convex QP.  Q is returned as its lower triangle (Qstype -1)."""
+    L = _genlib()
+    K = int(L.qpdo_gen_A_per_col(m, density))
+    nnzQ = int(L.qpdo_gen_Q_nnz(n, density))
+    Ap, Ai, Ax = np.empty(n + 1, np.int64), np.empty(n * K, np.int64), np.empty(n * K, np.float64)
+    Qp, Qi, Qx = np.empty(n + 1, np.int64), np.empty(nnzQ, np.int64), np.empty(nnzQ, np.float64)
+    q, l, u = np.empty(n), np.empty(m), np.empty(m)
+    ip, dp = C.POINTER(C.c_int64), C.POINTER(C.c_double)
+    L.qpdo_gen_problem(int(seed), n, m, float(density), int(n_eq),
+                       Ap.ctypes.data_as(ip), Ai.ctypes.data_as(ip), Ax.ctypes.data_as(dp),
+                       Qp.ctypes.data_as(ip), Qi.ctypes.data_as(ip), Qx.ctypes.data_as(dp),
+                       q.ctypes.data_as(dp), l.ctypes.data_as(dp), u.ctypes.data_as(dp))
+    A = sp.csc_matrix((Ax, Ai, Ap), shape=(m, n))
+    Q = sp.csc_matrix((Qx, Qi, Qp), shape=(n, n))
+    return dict(n=n, m=m, Q=Q, Qstype=-1, A=A, q=q, l=l, u=u, c=0.0, seed=int(seed))
+
+
+def config_qp(name, index=0):
+    cfg = CONFIGS[name]
+    seed = BASE_SEED + 1000 * (list(CONFIGS).index(name) + 1) + index
+    return random_qp(seed, cfg["n"], cfg["m"], cfg["density"], cfg["n_eq"])
+
+
+def full_Q(prob):
+    """Dense-free full symmetric Q from the stored triangle."""
+    Q = prob["Q"]
+    st = prob.get("Qstype", -1)
+    if st == 0:
+        return Q.tocsc()
+    T = sp.tril(Q) if st < 0 else sp.triu(Q)
+    return (T + T.T - sp.diags(T.diagonal())).tocsc()
+
+
+def infeasibility_kat(case):
+    """case in {'degenerate','primal_infeasible','dual_infeasible'}; expected status 1 / -3 / -4
+    (reference examples/infeasibility_tests.m:30,48,75)."""
+    a, b, c, expected = {
+        "degenerate": (0.0, 3.0, 0.0, 1),
+        "primal_infeasible": (1.0, 3.0, 0.0, -3),
+        "dual_infeasible": (0.0, np.inf, -1.0, -4),
+    }[case]
+    Qd = np.array([[1.0, 0.0], [0.0, 0.0]])
+    Ad = np.array([[a, a], [1.0, 0.0], [0.0, 1.0]])
+    Q = sp.csc_matrix(sp.tril(sp.csc_matrix(Qd)))
+    A = sp.csc_matrix(Ad)
+    Q.eliminate_zeros()
+    A.eliminate_zeros()
+    l = np.clip(np.array([-np.inf, 1.0, 1.0]), -QPDO_INFTY, QPDO_INFTY)
+    u = np.clip(np.array([0.0, 3.0, b]), -QPDO_INFTY, QPDO_INFTY)
+    return dict(n=2, m=3, Q=Q, Qstype=-1, A=A, q=np.array([1.0, c]), l=l, u=u, c=0.0,
+                expected_status=expected, max_iter=100)
+
+
+def kkt_residuals(prob, x, y):
+    """Unscaled outer residuals as the reference's demo recomputes them
+    (examples/demo_mex.m:39-40): ||Ax - clip(Ax+y)||inf, ||Qx+q+A'y||inf."""
+    A, Qf = prob["A"], full_Q(prob)
+    Ax = A @ x
+    rp = np.abs(Ax - np.clip(Ax + y, prob["l"], prob["u"])).max() if prob["m"] else 0.0
+    rd = np.abs(Qf @ x + prob["q"] + A.T @ y).max() if prob["n"] else 0.0
+    return float(rp), float(rd)
