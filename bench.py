@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Newton iterations/sec (+ time-to-eps) of the HIP path on a seeded
+random sparse QP, one process per GPU.
+
+A "step" is one full cold-start qpdo_solve to eps_abs = 1e-6 (reference defaults, include/constants.h)
+on the workload; `value` = Newton passes (loop passes that ran update_iterate) of all timed solves of all
+ranks / wall time (max over ranks); `ms_per_step` = time-to-eps.  Inputs are resident in HBM before
+the timed region starts (qpdo_setup uploads, converts and scales them; that time is reported separately as
+setup_s).  N > 1: independent QPs (different seeds) per rank, no data-path collective ("weak").
+
+Adds to the JSON line:
+  roofline     -- HBM roofline of the dominant kernel (the A' CSR SpMV inside PCG): algorithmic bytes
+                  12 nnz + 4(rows+1) + 8 rows + 8 cols over the HIP-event duration sampled live in the timed solves.
+  cpu_baseline -- the CPU oracle (a port; the reference needs CHOLMOD, absent here) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--workload", default=os.environ.get("QPDO_BENCH_WORKLOAD", "C4"),
+                    help="C4 (n=1e5,m=2e5,1%%: the config the metric is quoted on), C2, C1 ...")
+    ap.add_argument("--max-time", type=float, default=float(os.environ.get("QPDO_BENCH_MAX_TIME", "0")),
+                    help="settings.max_time per solve in seconds (0 = reference default, unlimited)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="bound of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    os.environ.setdefault("QPDO_DEVICE", str(local))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # control plane only (barrier + max of the wall time): the data path has no collective
+        dist_mod.init_process_group(backend=os.environ.get("QPDO_BENCH_BACKEND", "gloo"), rank=rank, world_size=world)
+        dist = dist_mod
+    return rank, world, dist
+
+
+def barrier(dist):
+    if dist is not None:
+        dist.barrier()
+
+
+def allreduce(dist, vals, op="sum"):
+    if dist is None:
+        return list(vals)
+    import torch
+    t = torch.tensor(list(vals), dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return t.tolist()
+
+
+def cpu_baseline(prob, seconds, cg_per_newton):
+    """Bounded sample on this host's cores: `seconds` of the oracle's Jacobi-PCG on the same matrices
+    (scaling off: the CG iteration cost does not depend on the scaling values), single thread."""
+    from oracle import binding as ob
+    s = ob.default_settings(scaling=0, max_time=seconds)
+    o = ob.OracleSolver(prob, s, linsolve="pcg", pcg_tol=1e-12)
+    o.set_deadline(seconds)
+    t0 = time.time()
+    o.solve()
+    dt = time.time() - t0
+    info = o.info()
+    cg = info["lin_iters"]
+    o.close()
+    cg_rate = cg / dt if dt > 0 else 0.0
+    newton_rate = cg_rate / cg_per_newton if cg_per_newton > 0 else None
+    return dict(value=newton_rate, unit="newton_iters/s", cores=1, kind="port",
+                sample=("%.1f s of the oracle's Jacobi-PCG on the same instance (scaling off, 1 thread): %d CG iterations "
+                        "= %.3f CG it/s, divided by the %.1f CG iterations per Newton pass the GPU run needed; the reference's "
+                        "own direct CHOLMOD path is not buildable here and would need ~80 GB / 3.3e14 flop per factor at C4"
+                        % (dt, cg, cg_rate, cg_per_newton)),
+                cg_iters_per_s=cg_rate)
+
+
+def main():
+    a = parse()
+    rank, world, dist = dist_setup(a.gpus)
+    from qpdo_amd import problems, solver
+    cfg = problems.CONFIGS[a.workload]
+    t0 = time.time()
+    prob = problems.config_qp(a.workload, index=rank)
+    t_gen = time.time() - t0
+    st = dict(verbose=0)
+    if a.max_time > 0:
+        st["max_time"] = a.max_time
+    t0 = time.time()
+    s = solver.QPDO().setup(prob["Q"], prob["q"], prob["A"], prob["l"], prob["u"], Qstype=-1, **st)
+    t_setup = time.time() - t0
+    L = solver.lib()
+
+    for _ in range(a.warmup):
+        s.solve()
+    L.qpdo_amd_sync(s._w)
+    barrier(dist)
+    t0 = time.time()
+    newton = cg = 0
+    iters = oters = 0
+    statuses = []
+    at_time = at_n = 0.0
+    for _ in range(a.steps):
+        r = s.solve()
+        stt = s.stats()
+        newton += stt["newton_passes"]; cg += stt["lin_iters"]
+        iters += r["info"]["iterations"]; oters += r["info"]["oterations"]
+        statuses.append(r["info"]["status_val"])
+        at_time += stt["spmv_At_avg_s"] * stt["spmv_At_samples"]; at_n += stt["spmv_At_samples"]
+    L.qpdo_amd_sync(s._w)
+    barrier(dist)
+    dt = time.time() - t0
+    dt_max = allreduce(dist, [dt], "max")[0]
+    tot_newton, tot_cg = allreduce(dist, [newton, cg], "sum")
+
+    last = r
+    rp, rd = problems.kkt_residuals(prob, last["x"], last["y"]) if last["info"]["status_val"] not in (-3, -4) else (None, None)
+    # roofline of the dominant kernel: A' SpMV (CSR n x m).  Live samples from the timed solves; a back-to-back
+    # micro-benchmark of the same kernel is reported beside it.
+    bench_t, alg_bytes = s.bench_spmv(1, reps=20)
+    live_t = at_time / at_n if at_n else bench_t
+    achieved = alg_bytes / live_t / 1e9
+    roof = dict(bound="hbm", kernel="k_spmv_pcg<64,EpiPcgAt> (y = A' t, CSR n x m)", achieved=achieved, peak=HBM_PEAK_GBS,
+                unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None, alg_bytes_per_launch=alg_bytes,
+                avg_launch_s=live_t, samples=int(at_n), microbench_GBs=alg_bytes / bench_t / 1e9,
+                spmv_A_GBs=None, spmv_Q_GBs=None)
+    for which, key in ((0, "spmv_A_GBs"), (2, "spmv_Q_GBs")):
+        t_, b_ = s.bench_spmv(which, reps=20)
+        roof[key] = b_ / t_ / 1e9
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "primal-dual Newton iters/sec (+ time-to-eps) on random sparse QP",
+            "value": tot_newton / dt_max if dt_max > 0 else 0.0,
+            "unit": "newton_iters/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt_max / max(1, a.steps),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic (seeded counter-based generator, qpdo_amd/csrc/qpdo_gen.c)",
+            "config": {"workload": "%s: one random sparse QP per GPU, n=%d, m=%d, density=%g, cold start, reference "
+                                   "default settings (eps_abs=1e-6, scaling=10)%s" % (
+                                       a.workload, cfg["n"], cfg["m"], cfg["density"],
+                                       (", max_time=%gs" % a.max_time) if a.max_time > 0 else ""),
+                       "n": cfg["n"], "m": cfg["m"], "density": cfg["density"], "linsolve": "jacobi-pcg" if s.stats()["linsolve"] == 0 else "dense-ldlt",
+                       "parallelism": "independent QPs per GPU, no collective"},
+            "time_to_eps_s": dt_max / max(1, a.steps) if all(v == 1 for v in statuses) else None,
+            "status_val": statuses, "iterations": iters, "oterations": oters, "newton_passes": tot_newton,
+            "cg_iters": tot_cg, "kkt_prim": rp, "kkt_dual": rd,
+            "setup_s": t_setup, "generate_s": t_gen,
+            "roofline": roof,
+        }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cgpn = (cg / newton) if newton else 0.0
+        try:
+            out["cpu_baseline"] = cpu_baseline(prob, a.cpu_seconds, cgpn)
+        except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU line
+            out["cpu_baseline"] = dict(value=None, unit="newton_iters/s", cores=1, kind="port", sample="failed: %r" % (e,))
+    s.delete()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

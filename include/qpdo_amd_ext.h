@@ -1,0 +1,70 @@
+/*
+ * qpdo_amd_ext.h -- extensions of libqpdo_amd.so beyond the reference API.
+ *
+ * Nothing here is needed to use the library as a drop-in for the reference;
+ * these entry points exist for measurement (bench.py), for the parity tests of
+ * single kernels, and for device selection.  All are plain C-ABI.
+ *
+ * Environment variables read once per qpdo_setup:
+ *   QPDO_DEVICE      HIP device ordinal (default: LOCAL_RANK if set, else 0)
+ *   QPDO_LINSOLVE    "pcg" | "dense" | "auto" (default auto: dense for n <= QPDO_DENSE_MAX_N)
+ *   QPDO_PCG_TOL     relative residual tolerance of the Jacobi-PCG solve (default 1e-12)
+ *   QPDO_PCG_MAXIT   PCG iteration cap per Newton step (default 100000)
+ *   QPDO_FIX_STATUS_RESET  "1": reset info->status_val at the start of qpdo_solve
+ *                    (the reference does not: src/qpdo.c:451-453 vs :200)
+ */
+#ifndef QPDO_AMD_EXT_H
+#define QPDO_AMD_EXT_H
+
+#include "qpdo.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* one record per loop pass of qpdo_solve (reference src/qpdo.c:343-449) */
+typedef struct {
+    long   kind;            /* 0 Newton step, 1 outer update, 2 terminated in this pass */
+    long   n_active, n_enter, n_leave;
+    long   factor_branch;   /* 0 full, 1 rank update, 2 Q only, -1 n/a (src/newton.c:21-33) */
+    long   lin_iters;       /* PCG iterations of this pass (0 for the dense solver)       */
+    double tau;
+    double res_prim, res_dual, res_prim_in, res_dual_in;
+    double sigma, eps_in;
+} QPDOAmdTraceRec;
+
+typedef struct {
+    long   newton_passes;   /* passes that ran update_iterate (iterations - oterations - final) */
+    long   lin_iters;       /* PCG iterations, all passes                                  */
+    long   spmv_calls;      /* SpMV launches in the last solve                             */
+    double spmv_alg_bytes;  /* sum over those launches of 12 nnz + 4(rows+1) + 8 rows + 8 cols */
+    long   factor_count;    /* dense LDL' factorizations                                   */
+    long   linsolve;        /* 0 pcg, 1 dense                                              */
+    double spmv_At_avg_s;   /* HIP-event average duration of the sampled A' SpMV inside PCG */
+    long   spmv_At_samples;
+} QPDOAmdStats;
+
+int  qpdo_amd_device_count(void);
+const char *qpdo_amd_last_error(void);
+int  qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out);
+/* trace of the last qpdo_solve; pointer stays valid until the next solve / cleanup */
+int  qpdo_amd_get_trace(const QPDOWorkspace *work, const QPDOAmdTraceRec **recs, long *count);
+int  qpdo_amd_sync(QPDOWorkspace *work);
+
+/* HIP-event timing of the SpMV kernel on the workspace's own (scaled) matrices.
+ * which: 0 = A (CSR m x n), 1 = A' (CSR n x m), 2 = Q (full symmetric CSR). */
+int  qpdo_amd_bench_spmv(QPDOWorkspace *work, int which, int reps, double *avg_seconds, double *alg_bytes);
+/* y = M v on the device, host in/out (parity tests) */
+int  qpdo_amd_spmv(QPDOWorkspace *work, int which, const double *v, double *y);
+/* root of eta t + beta + delta'[delta t - alpha]_+ over 2m breakpoints (reference
+ * src/linesearch.c:74-158) on the device, host in/out (parity tests) */
+int  qpdo_amd_linesearch(QPDOWorkspace *work, double eta, double beta, const double *delta,
+                         const double *alpha, double *tau);
+/* copy a device-resident vector to the host: 0 x, 1 Qx, 2 y, 3 mu, 4 d (factor weights),
+ * 5 dx, 6 dy, 7 Ax, 8 Aty, 9 l, 10 u */
+int  qpdo_amd_download(QPDOWorkspace *work, int which, double *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

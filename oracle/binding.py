@@ -56,6 +56,7 @@ def lib():
                                    dp, C.c_double, dp, dp, C.POINTER(OracleSettings)]
         L.oracle_set_linsolve.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int64]
         L.oracle_set_fix_status_reset.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_set_deadline.argtypes = [C.c_void_p, C.c_double]
         L.oracle_warm_start.argtypes = [C.c_void_p, dp, dp]
         L.oracle_solve.argtypes = [C.c_void_p]
         L.oracle_update_bounds.argtypes = [C.c_void_p, dp, dp]
@@ -158,6 +159,9 @@ class OracleSolver:
     def update_settings(self, settings):
         lib().oracle_update_settings(self.h, C.byref(settings))
         self.settings = settings
+
+    def set_deadline(self, seconds):
+        lib().oracle_set_deadline(self.h, float(seconds))
 
     def set_fix_status_reset(self, on):
         lib().oracle_set_fix_status_reset(self.h, int(on))

@@ -129,6 +129,7 @@ typedef struct {
     f64 *K;             /* dense n*n column-major, lower: L (unit) and D on diagonal */
     int linsolve;       /* 0 dense LDL', 1 Jacobi-PCG */
     f64 pcg_tol; i64 pcg_maxit;
+    f64 deadline;       /* absolute CLOCK_MONOTONIC seconds; 0 = none (cpu_baseline sampling only) */
     f64 *pc_r, *pc_z, *pc_p, *pc_Kp, *pc_diag, *pc_t;
     /* info */
     i64 iterations, oterations, status_val, newton_passes, lin_iters_total;
@@ -382,6 +383,8 @@ void oracle_set_linsolve(Oracle *o, int mode, f64 tol, i64 maxit) {
     if (maxit > 0) o->pcg_maxit = maxit;
 }
 void oracle_set_fix_status_reset(Oracle *o, int on) { o->fix_status_reset = on; }
+/* stop PCG (and, through settings.max_time, the solve) `seconds` from now */
+void oracle_set_deadline(Oracle *o, f64 seconds) { o->deadline = seconds > 0 ? now_s() + seconds : 0.0; }
 
 /* iteration.c:185-221 */
 static f64 compute_objective(Oracle *o) {
@@ -610,6 +613,7 @@ static i64 pcg_solve(Oracle *o, const f64 *b, f64 *x) {
     f64 rz = vec_prod(r, z, n);
     i64 it = 0;
     for (; it < o->pcg_maxit; it++) {
+        if (o->deadline > 0 && now_s() > o->deadline) break;
         K_apply(o, p, Kp);
         f64 alpha = rz / vec_prod(p, Kp, n);
         for (i64 i = 0; i < n; i++) { x[i] += alpha * p[i]; r[i] -= alpha * Kp[i]; }

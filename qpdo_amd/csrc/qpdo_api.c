@@ -1,0 +1,706 @@
+/*
+ * qpdo_api.c -- C host driver behind the qpdo.h C-ABI (the drop-in boundary).
+ *
+ * Mirrors the reference's public functions (src/qpdo.c) in name, argument
+ * meaning, ownership and error behaviour.  The driver keeps only scalars and
+ * the small host mirrors documented in include/qpdo.h; every vector and matrix
+ * operation is a HIP kernel reached through the thin C-ABI of qpdo_dev.h.
+ * There is no CPU fallback: if the device backend cannot be created,
+ * qpdo_setup returns NULL.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "qpdo.h"
+#include "qpdo_amd_ext.h"
+#include "qpdo_dev.h"
+
+struct QPDO_TIMER { struct timespec tic, toc; };   /* reference include/util.h:98-104 */
+
+struct QPDOBackend {
+    QpdoDev *dev;
+    int reset_newton;             /* reference chol->reset_newton (types.h:132) */
+    int fix_status_reset;
+    QPDOAmdTraceRec *trace; long ntrace, captrace;
+    long newton_passes;
+};
+
+#define c_max(a, b) (((a) > (b)) ? (a) : (b))
+#define c_min(a, b) (((a) < (b)) ? (a) : (b))
+#define c_absval(x) (((x) < 0) ? -(x) : (x))
+
+#define QPDO_PRINT(...) do { printf(__VA_ARGS__); fflush(stdout); } while (0)
+#define QPDO_EPRINT(...) do { printf("ERROR in %s: ", __func__); printf(__VA_ARGS__); printf("\n"); fflush(stdout); } while (0)
+
+/* ---- timing (reference src/util.c:245-264) ---------------------------------- */
+static void tic(QPDOTimer *t) { clock_gettime(CLOCK_MONOTONIC, &t->tic); }
+static c_float toc(QPDOTimer *t) {
+    clock_gettime(CLOCK_MONOTONIC, &t->toc);
+    return (c_float)(t->toc.tv_sec - t->tic.tv_sec) + 1e-9 * (c_float)(t->toc.tv_nsec - t->tic.tv_nsec);
+}
+
+/* ---- status strings (reference src/util.c:50-91) ------------------------------ */
+static void update_status(QPDOInfo *info, c_int status_val) {
+    const char *s;
+    info->status_val = status_val;
+    switch (status_val) {
+        case QPDO_SOLVED: s = "solved"; break;
+        case QPDO_DUAL_TERMINATED: s = "dual terminated"; break;
+        case QPDO_PRIMAL_INFEASIBLE: s = "primal infeasible"; break;
+        case QPDO_DUAL_INFEASIBLE: s = "dual infeasible"; break;
+        case QPDO_PRIMAL_DUAL_INFEASIBLE: s = "primal-dual infeasible"; break;
+        case QPDO_MAX_TIME_REACHED: s = "max time exceeded"; break;
+        case QPDO_MAX_ITER_REACHED: s = "maximum iterations reached"; break;
+        case QPDO_UNSOLVED: s = "unsolved"; break;
+        case QPDO_ERROR: s = "error"; break;
+        default: s = "unrecognised status value"; break;
+    }
+    strncpy(info->status, s, sizeof(info->status) - 1);
+    info->status[sizeof(info->status) - 1] = '\0';
+}
+
+/* ---- validation (reference src/validate.c:9-170) ------------------------------- */
+static int validate_data(const QPDOData *data) {
+    if (!data) { QPDO_EPRINT("Missing data"); return 0; }
+    for (size_t j = 0; j < data->m; j++)
+        if (data->l[j] > data->u[j]) {
+            QPDO_EPRINT("Lower bound at index %d is greater than upper bound: %.4e > %.4e", (int)j, data->l[j], data->u[j]);
+            return 0;
+        }
+    return 1;
+}
+static int validate_settings(const QPDOSettings *s) {
+    if (!s) { QPDO_EPRINT("Missing settings!"); return 0; }
+    if (s->max_iter <= 0) { QPDO_EPRINT("max_iter must be positive"); return 0; }
+    if (s->inner_max_iter <= 0) { QPDO_EPRINT("inner_max_iter must be positive"); return 0; }
+    if (s->eps_abs <= 0) { QPDO_EPRINT("eps_abs must be positive"); return 0; }
+    if (s->eps_abs_in <= 0) { QPDO_EPRINT("eps_abs_in must be positive"); return 0; }
+    if (s->eps_prim_inf < 0) { QPDO_EPRINT("eps_prim_inf must be nonnegative"); return 0; }
+    if (s->eps_dual_inf < 0) { QPDO_EPRINT("eps_dual_inf must be nonnegative"); return 0; }
+    if (s->rho <= 0 || s->rho >= 1) { QPDO_EPRINT("rho must be positive and smaller than 1"); return 0; }
+    if (s->theta <= 0 || s->theta > 1) { QPDO_EPRINT("theta must be positive and smaller than or equal to 1"); return 0; }
+    if (s->delta <= 0 || s->delta >= 1) { QPDO_EPRINT("delta must be positive and smaller than 1"); return 0; }
+    if (s->mu_min <= 0) { QPDO_EPRINT("mu_min must be positive"); return 0; }
+    if ((s->proximal != 0) && (s->proximal != 1)) { QPDO_EPRINT("proximal must be either 0 or 1"); return 0; }
+    if (s->sigma_init <= 0) { QPDO_EPRINT("sigma_init must be positive"); return 0; }
+    if (s->sigma_upd <= 0 || s->sigma_upd > 1) { QPDO_EPRINT("sigma_upd must be positive and smaller than or equal to 1"); return 0; }
+    if (s->sigma_min > s->sigma_init) { QPDO_EPRINT("sigma_min must be smaller than or equal to sigma_init"); return 0; }
+    if (s->scaling < 0) { QPDO_EPRINT("scaling must be nonnegative"); return 0; }
+    if (s->verbose < 0) { QPDO_EPRINT("verbose must be nonnegative"); return 0; }
+    if (s->print_interval < 0) { QPDO_EPRINT("print_interval must be nonnegative"); return 0; }
+    if (s->reset_newton_iter < 0) { QPDO_EPRINT("reset_newton_iter must be nonnegative"); return 0; }
+    return 1;
+}
+
+/* reference src/qpdo.c:24-44 with include/constants.h:44-69 */
+void qpdo_set_default_settings(QPDOSettings *s) {
+    s->max_time = QPDO_INFTY;
+    s->max_iter = 10000;
+    s->inner_max_iter = 1000;
+    s->eps_abs = 1e-6;
+    s->eps_abs_in = 1e0;
+    s->eps_prim_inf = 1e-6;
+    s->eps_dual_inf = 1e-6;
+    s->rho = 0.1;
+    s->theta = 0.25;
+    s->delta = 1e-2;
+    s->mu_min = 1e-9;
+    s->proximal = 1;
+    s->sigma_init = 1e-3;
+    s->sigma_upd = 1e-1;
+    s->sigma_min = 1e-7;
+    s->scaling = 10;
+    s->verbose = 1;
+    s->print_interval = 1;
+    s->reset_newton_iter = 1000;
+}
+static QPDOSettings *copy_settings(const QPDOSettings *s) {   /* src/util.c:21-45 */
+    QPDOSettings *n = malloc(sizeof(QPDOSettings));
+    if (n) *n = *s;
+    return n;
+}
+
+/* ---- matrix intake: CSC (int32 or int64 indices) -> int32 CSR triples ------------- */
+typedef struct { int32_t nrows, ncols; int64_t nnz; int32_t *rp, *ci; double *val; } HostCsr;
+static void host_csr_free(HostCsr *h) { free(h->rp); free(h->ci); free(h->val); memset(h, 0, sizeof(*h)); }
+static inline int64_t idx_at(const void *a, int itype, int64_t k) {
+    return itype == 0 ? (int64_t)((const int32_t *)a)[k] : (int64_t)((const int64_t *)a)[k];
+}
+static int sparse_ok(const cholmod_sparse *M) {
+    if (!M || !M->p) return 0;
+    if (M->itype != 0 && M->itype != 2) return 0;      /* CHOLMOD_INT / CHOLMOD_LONG */
+    if (M->xtype != 1 || M->dtype != 0) return 0;      /* real, double */
+    if (!M->packed && M->nz) return 0;                 /* unpacked storage not supported */
+    if (M->nrow >= (size_t)INT32_MAX || M->ncol >= (size_t)INT32_MAX) return 0;
+    if (idx_at(M->p, M->itype, (int64_t)M->ncol) >= (int64_t)INT32_MAX) return 0;
+    return 1;
+}
+/* the CSC arrays of an r x c matrix are the CSR arrays of its c x r transpose */
+static int csc_as_csr_of_transpose(const cholmod_sparse *M, HostCsr *out) {
+    const int64_t nc = (int64_t)M->ncol, nnz = idx_at(M->p, M->itype, nc);
+    memset(out, 0, sizeof(*out));
+    out->nrows = (int32_t)M->ncol; out->ncols = (int32_t)M->nrow; out->nnz = nnz;
+    out->rp = malloc(((size_t)nc + 1) * sizeof(int32_t));
+    out->ci = malloc((size_t)(nnz ? nnz : 1) * sizeof(int32_t));
+    out->val = malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
+    if (!out->rp || !out->ci || !out->val) { host_csr_free(out); return 0; }
+    for (int64_t j = 0; j <= nc; j++) out->rp[j] = (int32_t)idx_at(M->p, M->itype, j);
+    for (int64_t k = 0; k < nnz; k++) out->ci[k] = (int32_t)idx_at(M->i, M->itype, k);
+    memcpy(out->val, M->x, (size_t)nnz * sizeof(double));
+    return 1;
+}
+/* CSR of the r x c matrix itself: one counting pass, rows come out column-sorted */
+static int csc_to_csr(const cholmod_sparse *M, HostCsr *out) {
+    const int64_t nr = (int64_t)M->nrow, nc = (int64_t)M->ncol, nnz = idx_at(M->p, M->itype, nc);
+    memset(out, 0, sizeof(*out));
+    out->nrows = (int32_t)nr; out->ncols = (int32_t)nc; out->nnz = nnz;
+    out->rp = calloc((size_t)nr + 1, sizeof(int32_t));
+    out->ci = malloc((size_t)(nnz ? nnz : 1) * sizeof(int32_t));
+    out->val = malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
+    int32_t *next = malloc((size_t)(nr ? nr : 1) * sizeof(int32_t));
+    if (!out->rp || !out->ci || !out->val || !next) { free(next); host_csr_free(out); return 0; }
+    for (int64_t k = 0; k < nnz; k++) out->rp[idx_at(M->i, M->itype, k) + 1]++;
+    for (int64_t i = 0; i < nr; i++) out->rp[i + 1] += out->rp[i];
+    for (int64_t i = 0; i < nr; i++) next[i] = out->rp[i];
+    const double *x = M->x;
+    for (int64_t j = 0; j < nc; j++) {
+        const int64_t b = idx_at(M->p, M->itype, j), e = idx_at(M->p, M->itype, j + 1);
+        for (int64_t k = b; k < e; k++) {
+            const int32_t s = next[idx_at(M->i, M->itype, k)]++;
+            out->ci[s] = (int32_t)j; out->val[s] = x[k];
+        }
+    }
+    free(next);
+    return 1;
+}
+/* full symmetric CSR of Q from one stored triangle (stype -1 lower, +1 upper) or from full
+ * storage (stype 0).  Column-ordered fill keeps every row sorted by column. */
+static int sym_to_full_csr(const cholmod_sparse *Q, HostCsr *out) {
+    const int64_t n = (int64_t)Q->ncol, nnz_in = idx_at(Q->p, Q->itype, n);
+    const int st = Q->stype;
+    if (st == 0) return csc_as_csr_of_transpose(Q, out);      /* symmetric: transpose == itself */
+    memset(out, 0, sizeof(*out));
+    out->nrows = out->ncols = (int32_t)n;
+    out->rp = calloc((size_t)n + 1, sizeof(int32_t));
+    int32_t *next = malloc((size_t)(n ? n : 1) * sizeof(int32_t));
+    if (!out->rp || !next) { free(next); host_csr_free(out); return 0; }
+    int64_t total = 0;
+    for (int64_t j = 0; j < n; j++) {
+        const int64_t b = idx_at(Q->p, Q->itype, j), e = idx_at(Q->p, Q->itype, j + 1);
+        for (int64_t k = b; k < e; k++) {
+            const int64_t i = idx_at(Q->i, Q->itype, k);
+            if (i == j) { out->rp[i + 1]++; total++; }
+            else if ((st < 0 && i > j) || (st > 0 && i < j)) { out->rp[i + 1]++; out->rp[j + 1]++; total += 2; }
+        }
+    }
+    if (total >= (int64_t)INT32_MAX) { free(next); host_csr_free(out); return 0; }
+    (void)nnz_in;
+    for (int64_t i = 0; i < n; i++) out->rp[i + 1] += out->rp[i];
+    out->nnz = total;
+    out->ci = malloc((size_t)(total ? total : 1) * sizeof(int32_t));
+    out->val = malloc((size_t)(total ? total : 1) * sizeof(double));
+    if (!out->ci || !out->val) { free(next); host_csr_free(out); return 0; }
+    for (int64_t i = 0; i < n; i++) next[i] = out->rp[i];
+    const double *x = Q->x;
+    if (st < 0) {
+        /* lower stored: column j supplies (i<-j) for i>j into row i (ascending j), then row j takes its
+         * diagonal and the mirrored (j<-i), i ascending, after all its lower entries (columns < j). */
+        for (int64_t j = 0; j < n; j++) {
+            const int64_t b = idx_at(Q->p, Q->itype, j), e = idx_at(Q->p, Q->itype, j + 1);
+            for (int64_t k = b; k < e; k++) {       /* diagonal first so row j stays sorted */
+                const int64_t i = idx_at(Q->i, Q->itype, k);
+                if (i == j) { const int32_t s = next[j]++; out->ci[s] = (int32_t)j; out->val[s] = x[k]; }
+            }
+            for (int64_t k = b; k < e; k++) {
+                const int64_t i = idx_at(Q->i, Q->itype, k);
+                if (i > j) {
+                    int32_t s = next[i]++; out->ci[s] = (int32_t)j; out->val[s] = x[k];
+                    s = next[j]++; out->ci[s] = (int32_t)i; out->val[s] = x[k];
+                }
+            }
+        }
+    } else {
+        /* upper stored: entry (i,j), i<j.  Pass 1 (ascending j) fills the lower mirror (j<-i) ... rows
+         * would not come out sorted in one pass, so do two passes: lower mirrors + diagonal, then uppers. */
+        for (int64_t j = 0; j < n; j++) {
+            const int64_t b = idx_at(Q->p, Q->itype, j), e = idx_at(Q->p, Q->itype, j + 1);
+            for (int64_t k = b; k < e; k++) {
+                const int64_t i = idx_at(Q->i, Q->itype, k);
+                if (i < j) { const int32_t s = next[j]++; out->ci[s] = (int32_t)i; out->val[s] = x[k]; }
+            }
+            for (int64_t k = b; k < e; k++) {
+                const int64_t i = idx_at(Q->i, Q->itype, k);
+                if (i == j) { const int32_t s = next[j]++; out->ci[s] = (int32_t)j; out->val[s] = x[k]; }
+            }
+        }
+        for (int64_t j = 0; j < n; j++) {
+            const int64_t b = idx_at(Q->p, Q->itype, j), e = idx_at(Q->p, Q->itype, j + 1);
+            for (int64_t k = b; k < e; k++) {
+                const int64_t i = idx_at(Q->i, Q->itype, k);
+                if (i < j) { const int32_t s = next[i]++; out->ci[s] = (int32_t)j; out->val[s] = x[k]; }
+            }
+        }
+    }
+    free(next);
+    return 1;
+}
+
+/* ---- small host vector helpers (operation order of reference src/lin_alg.c) --------- */
+static c_float vec_norm_inf(const c_float *a, size_t n) {
+    c_float mx = 0.0;
+    for (size_t i = 0; i < n; i++) { c_float s = c_absval(a[i]); mx = s > mx ? s : mx; }
+    return mx;
+}
+static c_float *vec_dup(const c_float *a, size_t n) {
+    c_float *b = malloc((n ? n : 1) * sizeof(c_float));
+    if (b && n) memcpy(b, a, n * sizeof(c_float));
+    return b;
+}
+
+static int env_int(const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
+static double env_double(const char *name, double dflt) { const char *v = getenv(name); return (v && *v) ? atof(v) : dflt; }
+
+static QPDOAmdTraceRec *trace_push(struct QPDOBackend *b) {
+    if (b->ntrace == b->captrace) {
+        long cap = b->captrace ? 2 * b->captrace : 256;
+        QPDOAmdTraceRec *t = realloc(b->trace, (size_t)cap * sizeof(*t));
+        if (!t) return NULL;
+        b->trace = t; b->captrace = cap;
+    }
+    QPDOAmdTraceRec *r = &b->trace[b->ntrace++];
+    memset(r, 0, sizeof(*r));
+    r->factor_branch = -1;
+    return r;
+}
+
+/* apply this call's Ruiz/cost scaling to the host-side q,l,u mirrors and install the totals */
+static int install_scaling(QPDOWorkspace *work) {
+    size_t n = work->data->n, m = work->data->m;
+    QPDOScaling *sc = work->scaling;
+    for (size_t i = 0; i < n; i++) sc->Dinv[i] = (c_float)1.0 / sc->D[i];
+    for (size_t i = 0; i < m; i++) sc->Einv[i] = (c_float)1.0 / sc->E[i];
+    sc->cinv = (c_float)1.0 / sc->c;
+    return qdev_set_scaling(work->chol->dev, 1, sc->D, sc->Dinv, sc->E, sc->Einv, sc->c, sc->cinv);
+}
+
+/* ---- qpdo_setup (reference src/qpdo.c:49-212) ----------------------------------------- */
+QPDOWorkspace *qpdo_setup(const QPDOData *data, const QPDOSettings *settings) {
+    if (!validate_data(data)) { QPDO_EPRINT("Data validation returned failure"); return QPDO_NULL; }
+    if (!validate_settings(settings)) { QPDO_EPRINT("Settings validation returned failure"); return QPDO_NULL; }
+    if (!sparse_ok(data->Q) || !sparse_ok(data->A)) { QPDO_EPRINT("unsupported sparse matrix storage"); return QPDO_NULL; }
+    if (data->Q->nrow != data->n || data->Q->ncol != data->n || data->A->nrow != data->m || data->A->ncol != data->n) {
+        QPDO_EPRINT("matrix dimensions do not match n, m"); return QPDO_NULL;
+    }
+    QPDOWorkspace *work = calloc(1, sizeof(QPDOWorkspace));
+    if (!work) { QPDO_EPRINT("allocating work failure"); return QPDO_NULL; }
+    work->timer = malloc(sizeof(QPDOTimer));
+    if (!work->timer) { free(work); return QPDO_NULL; }
+    tic(work->timer);
+
+    const size_t n = data->n, m = data->m;
+    work->settings = copy_settings(settings);
+    work->chol = calloc(1, sizeof(struct QPDOBackend));
+    work->data = calloc(1, sizeof(QPDOData));
+    work->solution = calloc(1, sizeof(QPDOSolution));
+    work->info = calloc(1, sizeof(QPDOInfo));
+    if (!work->settings || !work->chol || !work->data || !work->solution || !work->info) goto fail;
+    work->sqrt_delta = sqrt(work->settings->delta);
+    work->sigma = work->settings->sigma_init;
+    work->data->n = n; work->data->m = m; work->data->c = data->c;
+    work->data->q = vec_dup(data->q, n);
+    work->data->l = vec_dup(data->l, m);
+    work->data->u = vec_dup(data->u, m);
+    work->x = calloc(n ? n : 1, sizeof(c_float));
+    work->y = calloc(m ? m : 1, sizeof(c_float));
+    work->dx = calloc(n ? n : 1, sizeof(c_float));
+    work->dy = calloc(m ? m : 1, sizeof(c_float));
+    work->solution->x = calloc(n ? n : 1, sizeof(c_float));
+    work->solution->y = calloc(m ? m : 1, sizeof(c_float));
+    if (!work->data->q || !work->data->l || !work->data->u || !work->x || !work->y || !work->dx || !work->dy ||
+        !work->solution->x || !work->solution->y) goto fail;
+    work->initialized = 0;
+    work->n_mu_changed = 0;
+    work->chol->reset_newton = 1;
+    work->chol->fix_status_reset = env_int("QPDO_FIX_STATUS_RESET", 0);
+
+    {   /* matrices to the device */
+        HostCsr Ar = {0}, At = {0}, Qf = {0};
+        int ok = csc_to_csr(data->A, &Ar);
+        ok = ok && csc_as_csr_of_transpose(data->A, &At);
+        ok = ok && sym_to_full_csr(data->Q, &Qf);
+        if (!ok) { host_csr_free(&Ar); host_csr_free(&At); host_csr_free(&Qf); QPDO_EPRINT("matrix conversion failed"); goto fail; }
+        QdevCsr a = {Ar.nrows, Ar.ncols, Ar.nnz, Ar.rp, Ar.ci, Ar.val};
+        QdevCsr t = {At.nrows, At.ncols, At.nnz, At.rp, At.ci, At.val};
+        QdevCsr qf = {Qf.nrows, Qf.ncols, Qf.nnz, Qf.rp, Qf.ci, Qf.val};
+        int device = env_int("QPDO_DEVICE", env_int("LOCAL_RANK", 0));
+        int ndev = qdev_device_count();
+        if (ndev <= 0) {
+            host_csr_free(&Ar); host_csr_free(&At); host_csr_free(&Qf);
+            QPDO_EPRINT("no HIP device available (this library has no CPU path)"); goto fail;
+        }
+        device = device % ndev;
+        int rc = qdev_create(&work->chol->dev, device, (int32_t)n, (int32_t)m, &a, &t, &qf, work->data->q, work->data->l, work->data->u);
+        host_csr_free(&Ar); host_csr_free(&At); host_csr_free(&Qf);
+        if (rc) { QPDO_EPRINT("device backend: %s", qdev_last_error()); goto fail; }
+        const char *ls = getenv("QPDO_LINSOLVE");
+        int mode = -1;
+        if (ls && !strcmp(ls, "pcg")) mode = 0; else if (ls && !strcmp(ls, "dense")) mode = 1;
+        qdev_configure(work->chol->dev, mode, env_double("QPDO_PCG_TOL", 0.0), env_int("QPDO_PCG_MAXIT", 0));
+    }
+
+    if (settings->scaling) {
+        work->scaling = malloc(sizeof(QPDOScaling));
+        if (!work->scaling) goto fail;
+        work->scaling->D = calloc(n ? n : 1, sizeof(c_float));
+        work->scaling->Dinv = calloc(n ? n : 1, sizeof(c_float));
+        work->scaling->E = calloc(m ? m : 1, sizeof(c_float));
+        work->scaling->Einv = calloc(m ? m : 1, sizeof(c_float));
+        if (!work->scaling->D || !work->scaling->Dinv || !work->scaling->E || !work->scaling->Einv) goto fail;
+        /* scale_data (scaling.c:24-91): A, Q, q on the device; l, u through the host mirrors */
+        if (qdev_scale_data(work->chol->dev, (int)settings->scaling, 0, work->scaling->D, work->scaling->E, &work->scaling->c)) goto fail_dev;
+        if (install_scaling(work)) goto fail_dev;
+        if (qdev_download_q(work->chol->dev, work->data->q)) goto fail_dev;
+        for (size_t i = 0; i < m; i++) { work->data->l[i] = work->scaling->E[i] * work->data->l[i]; work->data->u[i] = work->scaling->E[i] * work->data->u[i]; }
+        if (qdev_upload_bounds(work->chol->dev, work->data->l, work->data->u)) goto fail_dev;
+        {   /* || Dinv q || (qpdo.c:163-165) */
+            c_float mx = 0.0;
+            for (size_t i = 0; i < n; i++) { c_float s = c_absval(work->scaling->Dinv[i] * work->data->q[i]); mx = s > mx ? s : mx; }
+            work->norm_q = mx;
+        }
+    } else {
+        work->scaling = QPDO_NULL;
+        if (qdev_set_scaling(work->chol->dev, 0, NULL, NULL, NULL, NULL, 1.0, 1.0)) goto fail_dev;
+        work->norm_q = vec_norm_inf(work->data->q, n);
+    }
+    update_status(work->info, QPDO_UNSOLVED);
+    work->info->solve_time = 0.0;
+    work->info->run_time = 0.0;
+    work->info->setup_time = toc(work->timer);
+    return work;
+
+fail_dev:
+    QPDO_EPRINT("device backend: %s", qdev_last_error());
+fail:
+    qpdo_cleanup(work);
+    return QPDO_NULL;
+}
+
+/* ---- qpdo_warm_start (reference src/qpdo.c:217-299) --------------------------------------- */
+void qpdo_warm_start(QPDOWorkspace *work, c_float *x_warm_start, c_float *y_warm_start) {
+    work->sigma = work->settings->sigma_init;
+    if (work->info->status_val != QPDO_UNSOLVED) work->info->setup_time = 0;
+    tic(work->timer);
+    c_float obj = 0.0;
+    int rc = qdev_warm_start(work->chol->dev, x_warm_start, y_warm_start, (int)work->settings->proximal, work->sigma,
+                             work->settings->mu_min, work->data->c, &obj);
+    if (rc) { QPDO_EPRINT("device backend: %s", qdev_last_error()); update_status(work->info, QPDO_ERROR); return; }
+    work->info->objective = x_warm_start ? obj : 0.0;
+    work->sqrt_mu_min = 1 / sqrt(work->settings->mu_min);      /* iteration.c:121 */
+    work->initialized = 1;
+    work->info->setup_time += toc(work->timer);
+}
+
+/* reference src/util.c:101-117 */
+static void print_header(void) {
+    QPDO_PRINT("============================================================================\n");
+    QPDO_PRINT("===                    QPDO  v0.1  (MI355X-native backend)               ===\n");
+    QPDO_PRINT("============================================================================\n");
+    QPDO_PRINT("  iter |  objective     r.prim     r.dual |  r.p. in    r.d. in   stepsize | \n");
+    QPDO_PRINT("============================================================================\n");
+}
+static void print_iteration(c_int iter, QPDOWorkspace *work) {
+    QPDO_PRINT("%6ld | %+-.3e   %.2e   %.2e | %.2e   %.2e   %.2e | \n", (long)iter, work->info->objective, work->info->res_prim_norm,
+               work->info->res_dual_norm, work->info->res_prim_in_norm, work->info->res_dual_in_norm, work->tau);
+}
+static void print_final_message(QPDOWorkspace *work) {   /* src/util.c:122-173 */
+    const char *msg;
+    switch (work->info->status_val) {
+        case QPDO_SOLVED: msg = "QPDO finished successfully."; break;
+        case QPDO_PRIMAL_INFEASIBLE: msg = "QPDO detected a primal infeasible problem."; break;
+        case QPDO_DUAL_INFEASIBLE: msg = "QPDO detected a dual infeasible problem."; break;
+        case QPDO_PRIMAL_DUAL_INFEASIBLE: msg = "QPDO detected a primal-dual infeasible problem."; break;
+        case QPDO_MAX_ITER_REACHED: msg = "QPDO hit the maximum number of iterations."; break;
+        case QPDO_MAX_TIME_REACHED: msg = "QPDO exceeded the specified time limit."; break;
+        default: msg = "QPDO ended with an unrecognised status."; break;
+    }
+    QPDO_PRINT("============================================================================\n");
+    QPDO_PRINT("| %-72s |\n", msg);
+    QPDO_PRINT("| primal residual: %5.4e,                primal tolerance: %5.4e |\n", work->info->res_prim_norm, work->settings->eps_abs);
+    QPDO_PRINT("| dual residual  : %5.4e,                dual tolerance  : %5.4e |\n", work->info->res_dual_norm, work->settings->eps_abs);
+    QPDO_PRINT("| objective value: %+-5.4e                                             |\n", work->info->objective);
+    if (work->info->run_time > 1.0) QPDO_PRINT("| runtime:         %4.2f seconds\n", work->info->run_time);
+    else QPDO_PRINT("| runtime:         %4.2f milliseconds\n", work->info->run_time * 1000);
+    QPDO_PRINT("============================================================================\n\n");
+}
+
+#define DEVCALL(call) do { if ((call)) { QPDO_EPRINT("device backend: %s", qdev_last_error()); update_status(work->info, QPDO_ERROR); goto done; } } while (0)
+
+/* ---- qpdo_solve (reference src/qpdo.c:304-476) ---------------------------------------------- */
+void qpdo_solve(QPDOWorkspace *work) {
+    struct QPDOBackend *be = work->chol;
+    QpdoDev *dev = be->dev;
+    const QPDOSettings *s;
+    if (work->settings->verbose) print_header();
+    if (!work->initialized) qpdo_warm_start(work, NULL, NULL);
+    s = work->settings;
+    const int prox = (int)s->proximal;
+    work->eps_in = s->eps_abs_in;
+    work->sigma = s->sigma_init;
+    be->reset_newton = 1;
+    if (be->fix_status_reset) update_status(work->info, QPDO_UNSOLVED);
+    tic(work->timer);
+    be->ntrace = 0; be->newton_passes = 0;
+    qdev_reset_stats(dev);
+    c_int iter = 0, oter = 0, iter_old = 0;
+    if (!work->initialized) goto done;      /* warm start failed on the device */
+    DEVCALL(qdev_begin_solve(dev));
+
+    for (iter = 0; iter < s->max_iter; iter++) {
+        QdevResid r;
+        DEVCALL(qdev_residuals(dev, prox, work->sigma, &r));
+        work->info->res_prim_norm = r.res_prim; work->info->res_dual_norm = r.res_dual;
+        work->info->res_prim_in_norm = r.res_prim_in; work->info->res_dual_in_norm = r.res_dual_in;
+        QPDOAmdTraceRec *tr = trace_push(be);
+        if (tr) {
+            tr->kind = 2; tr->res_prim = r.res_prim; tr->res_dual = r.res_dual; tr->res_prim_in = r.res_prim_in;
+            tr->res_dual_in = r.res_dual_in; tr->sigma = work->sigma; tr->eps_in = work->eps_in;
+        }
+        if (s->verbose && (s->print_interval > 0) && (iter % s->print_interval == 0)) {
+            DEVCALL(qdev_objective(dev, prox, work->sigma, work->data->c, &work->info->objective));
+            print_iteration(iter, work);
+        }
+        /* check_outer_optimality (termination.c:11-23) */
+        if ((r.res_prim > QPDO_INFTY) || (r.res_dual > QPDO_INFTY)) { update_status(work->info, QPDO_NON_CVX); break; }
+        if ((r.res_prim <= s->eps_abs) && (r.res_dual <= s->eps_abs)) { update_status(work->info, QPDO_SOLVED); break; }
+        const int inner_opt = (r.res_prim_in <= work->eps_in) && (r.res_dual_in <= work->eps_in);   /* termination.c:28-30 */
+
+        if (((iter > iter_old + 1) && inner_opt) || (iter == iter_old + s->inner_max_iter)) {
+            if (tr) tr->kind = 1;
+            if (iter < iter_old + s->inner_max_iter) {
+                if (s->eps_prim_inf > 0) {
+                    int inf = 0;
+                    DEVCALL(qdev_primal_infeasibility(dev, s->eps_prim_inf, &inf));
+                    if (inf) { update_status(work->info, QPDO_PRIMAL_INFEASIBLE); break; }
+                }
+                if (s->eps_dual_inf > 0) {
+                    int inf = 0;
+                    DEVCALL(qdev_dual_infeasibility(dev, prox, work->sigma, work->tau, s->eps_dual_inf, &inf));
+                    if (inf) { update_status(work->info, QPDO_DUAL_INFEASIBLE); break; }
+                }
+            }
+            DEVCALL(qdev_shift_estimates(dev));
+            if ((oter > 0) && (r.res_prim > s->eps_abs)) {
+                /* update_mu (iteration.c:127-168) */
+                int nch = 0;
+                DEVCALL(qdev_update_mu(dev, s->eps_abs, s->theta, s->delta, s->mu_min, work->sqrt_mu_min, &nch));
+                work->n_mu_changed = nch;
+                if ((prox && work->sigma > s->sigma_min) || (nch > 0.25 * QPDO_MAX_RANK_UPDATE)) be->reset_newton = 1;
+                else if (nch == 0) { /* nothing */ }
+                else DEVCALL(qdev_mu_changed_update(dev));
+            }
+            if (prox && (oter > 0) && (r.res_dual > s->eps_abs)) {
+                /* update_sigma (iteration.c:173-180) */
+                if (work->sigma > s->sigma_min) {
+                    c_float sigma_old = work->sigma;
+                    work->sigma = c_max(work->sigma * s->sigma_upd, s->sigma_min);
+                    be->reset_newton = 1;
+                    DEVCALL(qdev_update_sigma(dev, work->sigma, sigma_old));
+                }
+            }
+            if (iter < iter_old + s->inner_max_iter) {
+                work->eps_in = c_max(s->rho * work->eps_in, 0.1 * s->eps_abs);
+                if (s->verbose && (s->print_interval > 0) && (iter % s->print_interval == 0))
+                    QPDO_PRINT("%6ld |-------------------------------------------------------------------|\n", (long)iter);
+            } else if (s->verbose && (s->print_interval > 0) && (iter % s->print_interval == 0)) {
+                QPDO_PRINT("%6ld |--  --  --  --  --  --  --  --  --  --  --  --  --  --  --  --  -- |\n", (long)iter);
+            }
+            DEVCALL(qdev_save_res_prim(dev));
+            oter++;
+            iter_old = iter;
+        } else {
+            if (tr) tr->kind = 0;
+            /* the reference computes iter % reset_newton_iter, a division by zero for the (valid) setting 0;
+             * here 0 means "no periodic refactorization" */
+            if (s->reset_newton_iter > 0 && (iter % s->reset_newton_iter == 0)) be->reset_newton = 1;
+            /* factorization decision (newton.c:21-33) */
+            int branch;
+            if ((be->reset_newton && r.n_active) || (r.n_enter + r.n_leave) > QPDO_MAX_RANK_UPDATE) { be->reset_newton = 0; branch = 0; }
+            else if (r.n_active) branch = 1;
+            else branch = 2;
+            int lin = 0;
+            DEVCALL(qdev_newton_step(dev, branch, prox, work->sigma, &work->tau, &lin));
+            be->newton_passes++;
+            if (tr) { tr->tau = work->tau; tr->n_active = r.n_active; tr->n_enter = r.n_enter; tr->n_leave = r.n_leave; tr->factor_branch = branch; tr->lin_iters = lin; }
+        }
+        work->info->run_time = work->info->setup_time + toc(work->timer);
+        if (work->info->run_time > s->max_time) { update_status(work->info, QPDO_MAX_TIME_REACHED); break; }
+    }
+    if (work->info->status_val == QPDO_UNSOLVED) update_status(work->info, QPDO_MAX_ITER_REACHED);
+
+done:
+    work->info->iterations = iter;
+    work->info->oterations = oter;
+    /* store_solution (termination.c:82-92) + host mirrors */
+    if (qdev_store_solution(dev, work->solution->x, work->solution->y, work->x, work->y, work->dx, work->dy) ||
+        qdev_objective(dev, prox, work->sigma, work->data->c, &work->info->objective)) {
+        QPDO_EPRINT("device backend: %s", qdev_last_error());
+        update_status(work->info, QPDO_ERROR);
+    }
+    work->initialized = 0;
+    work->info->solve_time = toc(work->timer);
+    work->info->run_time = work->info->setup_time + work->info->solve_time;
+    if (work->settings->verbose) {
+        if (work->settings->print_interval > 0 && (iter % work->settings->print_interval != 0)) print_iteration(iter, work);
+        print_final_message(work);
+    }
+}
+
+/* ---- qpdo_update_settings (reference src/qpdo.c:481-517) --------------------------------------- */
+void qpdo_update_settings(QPDOWorkspace *work, const QPDOSettings *settings) {
+    if (!validate_settings(settings)) {
+        QPDO_EPRINT("Settings validation returned failure");
+        update_status(work->info, QPDO_ERROR);
+        return;
+    }
+    if (work->settings->scaling > settings->scaling) {
+        QPDO_EPRINT("Decreasing the number of scaling iterations is not allowed");
+        update_status(work->info, QPDO_ERROR);
+        return;
+    } else if (work->settings->scaling < settings->scaling) {
+        if (!work->scaling) {   /* the reference dereferences NULL here (qpdo.c:496-499) */
+            QPDO_EPRINT("scaling cannot be enabled after setup");
+            update_status(work->info, QPDO_ERROR);
+            return;
+        }
+        size_t n = work->data->n, m = work->data->m;
+        c_float *Dsave = vec_dup(work->scaling->D, n), *Esave = vec_dup(work->scaling->E, m);
+        c_float c_temp = work->scaling->c, c_new = 1.0;
+        if (!Dsave || !Esave || qdev_scale_data(work->chol->dev, (int)(settings->scaling - work->settings->scaling), 1,
+                                                 work->scaling->D, work->scaling->E, &c_new)) {
+            free(Dsave); free(Esave);
+            update_status(work->info, QPDO_ERROR);
+            return;
+        }
+        /* bounds: l,u <- E_new .* l,u on the host mirrors (scaling.c:86-87) */
+        for (size_t i = 0; i < m; i++) { work->data->l[i] = work->scaling->E[i] * work->data->l[i]; work->data->u[i] = work->scaling->E[i] * work->data->u[i]; }
+        for (size_t i = 0; i < n; i++) work->scaling->D[i] = work->scaling->D[i] * Dsave[i];
+        for (size_t i = 0; i < m; i++) work->scaling->E[i] = work->scaling->E[i] * Esave[i];
+        work->scaling->c = c_new * c_temp;
+        free(Dsave); free(Esave);
+        if (install_scaling(work) || qdev_download_q(work->chol->dev, work->data->q) ||
+            qdev_upload_bounds(work->chol->dev, work->data->l, work->data->u)) {
+            update_status(work->info, QPDO_ERROR);
+            return;
+        }
+    }
+    free(work->settings);
+    work->settings = copy_settings(settings);
+    work->sqrt_delta = sqrt(work->settings->delta);
+}
+
+/* ---- qpdo_update_bounds (reference src/qpdo.c:522-544) ------------------------------------------ */
+void qpdo_update_bounds(QPDOWorkspace *work, const c_float *l, const c_float *u) {
+    size_t m = work->data->m;
+    if (l != NULL && u != NULL) {
+        for (size_t j = 0; j < m; j++) {
+            if (l[j] > u[j]) {
+                QPDO_EPRINT("Lower bound at index %d is greater than upper bound: %.4e > %.4e", (int)j, l[j], u[j]);
+                update_status(work->info, QPDO_ERROR);
+                return;
+            }
+        }
+    }
+    if (l != NULL) memcpy(work->data->l, l, m * sizeof(c_float));
+    if (u != NULL) memcpy(work->data->u, u, m * sizeof(c_float));
+    if (work->settings->scaling) {
+        if (l != NULL) for (size_t i = 0; i < m; i++) work->data->l[i] = work->scaling->E[i] * work->data->l[i];
+        if (u != NULL) for (size_t i = 0; i < m; i++) work->data->u[i] = work->scaling->E[i] * work->data->u[i];
+    }
+    if (qdev_upload_bounds(work->chol->dev, l ? work->data->l : NULL, u ? work->data->u : NULL)) update_status(work->info, QPDO_ERROR);
+}
+
+/* ---- qpdo_update_q (reference src/qpdo.c:549-586) ------------------------------------------------- */
+void qpdo_update_q(QPDOWorkspace *work, const c_float *q) {
+    size_t n = work->data->n;
+    QpdoDev *dev = work->chol->dev;
+    memcpy(work->data->q, q, n * sizeof(c_float));
+    if (work->settings->scaling) {
+        c_float *Qx = malloc((n ? n : 1) * sizeof(c_float)), *x = malloc((n ? n : 1) * sizeof(c_float));
+        if (!Qx || !x || qdev_download_vec(dev, 1, Qx) || qdev_download_vec(dev, 0, x)) { free(Qx); free(x); update_status(work->info, QPDO_ERROR); return; }
+        for (size_t i = 0; i < n; i++) work->data->q[i] = work->scaling->D[i] * work->data->q[i];
+        c_float c_old = work->scaling->c;
+        if (work->settings->proximal) for (size_t i = 0; i < n; i++) Qx[i] = Qx[i] + (-work->sigma) * x[i];
+        c_float mx = 0.0;
+        for (size_t i = 0; i < n; i++) { c_float t = work->data->q[i] + work->scaling->cinv * Qx[i]; c_float s = c_absval(t); mx = s > mx ? s : mx; }
+        work->scaling->c = 1 / c_max(1.0, mx);
+        work->scaling->cinv = 1 / work->scaling->c;
+        for (size_t i = 0; i < n; i++) work->data->q[i] *= work->scaling->c;
+        const c_float f = work->scaling->c / c_old;
+        for (size_t i = 0; i < n; i++) Qx[i] *= f;
+        if (work->settings->proximal) {
+            work->sigma = work->settings->sigma_init;
+            for (size_t i = 0; i < n; i++) Qx[i] = Qx[i] + work->sigma * x[i];
+        }
+        int rc = qdev_scale_Q_values(dev, f) || qdev_upload_vec(dev, 1, Qx) || qdev_upload_q(dev, work->data->q) ||
+                 qdev_set_scaling(dev, 1, work->scaling->D, work->scaling->Dinv, work->scaling->E, work->scaling->Einv,
+                                  work->scaling->c, work->scaling->cinv);
+        c_float nq = 0.0;
+        for (size_t i = 0; i < n; i++) { c_float s = c_absval(work->scaling->Dinv[i] * work->data->q[i]); nq = s > nq ? s : nq; }
+        work->norm_q = nq;
+        free(Qx); free(x);
+        if (rc) update_status(work->info, QPDO_ERROR);
+    } else {
+        if (qdev_upload_q(dev, work->data->q)) update_status(work->info, QPDO_ERROR);
+        work->norm_q = vec_norm_inf(work->data->q, n);
+    }
+}
+
+/* ---- qpdo_cleanup (reference src/qpdo.c:591-689) ---------------------------------------------------- */
+void qpdo_cleanup(QPDOWorkspace *work) {
+    if (!work) return;
+    if (work->data) { free(work->data->q); free(work->data->l); free(work->data->u); free(work->data); }
+    if (work->scaling) { free(work->scaling->D); free(work->scaling->Dinv); free(work->scaling->E); free(work->scaling->Einv); free(work->scaling); }
+    free(work->x); free(work->y); free(work->dx); free(work->dy);
+    free(work->settings);
+    if (work->chol) { qdev_destroy(work->chol->dev); free(work->chol->trace); free(work->chol); }
+    if (work->solution) { free(work->solution->x); free(work->solution->y); free(work->solution); }
+    free(work->timer);
+    free(work->info);
+    free(work);
+}
+
+/* ---- extensions (include/qpdo_amd_ext.h) --------------------------------------------------------------- */
+int qpdo_amd_device_count(void) { return qdev_device_count(); }
+const char *qpdo_amd_last_error(void) { return qdev_last_error(); }
+int qpdo_amd_sync(QPDOWorkspace *work) { return qdev_sync(work->chol->dev); }
+int qpdo_amd_get_trace(const QPDOWorkspace *work, const QPDOAmdTraceRec **recs, long *count) {
+    *recs = work->chol->trace; *count = work->chol->ntrace; return 0;
+}
+int qpdo_amd_bench_spmv(QPDOWorkspace *work, int which, int reps, double *avg_seconds, double *alg_bytes) {
+    return qdev_bench_spmv(work->chol->dev, which, reps, avg_seconds, alg_bytes);
+}
+int qpdo_amd_spmv(QPDOWorkspace *work, int which, const double *v, double *y) { return qdev_spmv(work->chol->dev, which, v, y); }
+int qpdo_amd_linesearch(QPDOWorkspace *work, double eta, double beta, const double *delta, const double *alpha, double *tau) {
+    return qdev_linesearch(work->chol->dev, eta, beta, delta, alpha, tau);
+}
+int qpdo_amd_download(QPDOWorkspace *work, int which, double *dst) { return qdev_download_vec(work->chol->dev, which, dst); }
+int qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out) {
+    QdevStats st;
+    double avg = 0.0; long ns = 0;
+    qdev_get_stats(work->chol->dev, &st);
+    qdev_get_spmv_sample(work->chol->dev, &avg, &ns);
+    out->newton_passes = work->chol->newton_passes;
+    out->lin_iters = (long)st.lin_iters;
+    out->spmv_calls = (long)st.spmv_calls;
+    out->spmv_alg_bytes = (double)st.spmv_bytes;
+    out->factor_count = (long)st.factor_count;
+    out->linsolve = st.linsolve;
+    out->spmv_At_avg_s = avg;
+    out->spmv_At_samples = ns;
+    return 0;
+}

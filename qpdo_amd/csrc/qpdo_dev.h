@@ -1,0 +1,126 @@
+/*
+ * qpdo_dev.h -- thin C-ABI between the C host driver (qpdo_api.c) and the HIP
+ * backend (qpdo_dev.hip).  Plain pointers and sizes only.  Every call returns 0
+ * on success and a non-zero HIP error code otherwise; the driver maps failures
+ * to QPDO_ERROR / NULL.
+ *
+ * Each entry point corresponds to one phase of the reference's hot path; the
+ * reference lines it replaces are cited at the definition in qpdo_dev.hip.
+ */
+#ifndef QPDO_DEV_H
+#define QPDO_DEV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct QpdoDev QpdoDev;
+
+/* host-side CSR triple handed to the device at setup (int32 indices) */
+typedef struct {
+    int32_t nrows, ncols;
+    int64_t nnz;
+    const int32_t *rp;    /* nrows+1 */
+    const int32_t *ci;    /* nnz */
+    const double  *val;   /* nnz */
+} QdevCsr;
+
+/* norms and counts produced by one residual pass */
+typedef struct {
+    double res_prim, res_dual, res_prim_in, res_dual_in;   /* inf-norms, un-scaled by Einv / Dinv */
+    int32_t n_active, n_enter, n_leave;
+} QdevResid;
+
+/* per-solve device statistics (extension; see include/qpdo_amd_ext.h) */
+typedef struct {
+    int64_t newton_passes;
+    int64_t lin_iters;          /* PCG iterations, summed                    */
+    int64_t spmv_calls;         /* SpMV launches                             */
+    int64_t spmv_bytes;         /* algorithmic bytes moved by those launches */
+    int64_t factor_count;       /* dense LDL' factorizations                 */
+    int32_t linsolve;           /* 0 pcg, 1 dense                            */
+} QdevStats;
+
+int qdev_device_count(void);
+const char *qdev_last_error(void);
+
+/* Ar = CSR(A) m x n, At = CSR(A') n x m, Qf = full symmetric CSR(Q) n x n.  q,l,u unscaled. */
+int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m,
+                const QdevCsr *Ar, const QdevCsr *At, const QdevCsr *Qf,
+                const double *q, const double *l, const double *u);
+void qdev_destroy(QpdoDev *d);
+int qdev_sync(QpdoDev *d);
+
+/* Ruiz equilibration + cost scaling (reference scaling.c:24-91).  Runs `iters` more
+ * iterations on the current data; D,E (host, out) receive this call's factors, c_out the
+ * cost scale.  Qx_nonzero: use the workspace Qx in the cost norm (update_settings path). */
+int qdev_scale_data(QpdoDev *d, int iters, int use_Qx, double *D_host, double *E_host, double *c_out);
+/* install total scaling vectors (after update_settings composed them on the host) */
+int qdev_set_scaling(QpdoDev *d, int scaled, const double *D, const double *Dinv,
+                     const double *E, const double *Einv, double c, double cinv);
+int qdev_upload_bounds(QpdoDev *d, const double *l, const double *u);   /* already scaled */
+int qdev_upload_q(QpdoDev *d, const double *q);                          /* already scaled */
+int qdev_download_q(QpdoDev *d, double *q);
+int qdev_scale_Q_values(QpdoDev *d, double factor);                      /* qpdo.c:566-572 */
+
+/* warm start (qpdo.c:217-299): x_ws / y_ws may be NULL.  Returns objective. */
+int qdev_warm_start(QpdoDev *d, const double *x_ws, const double *y_ws, int proximal,
+                    double sigma, double mu_min, double c_const, double *objective);
+
+/* begin a solve: clear old active set (qpdo.c:321-322) */
+int qdev_begin_solve(QpdoDev *d);
+
+/* outer + inner residuals, norms, active-set counts (iteration.c:30-93, termination.c:35-77,
+ * newton.c:96-126) */
+int qdev_residuals(QpdoDev *d, int proximal, double sigma, QdevResid *out);
+
+/* one Newton step (iteration.c:11-25): factor-state update, direction, exact linesearch,
+ * iterate update.  branch: 0 full (d = active/mu), 1 rank update (enter/leave), 2 Q only. */
+int qdev_newton_step(QpdoDev *d, int branch, int proximal, double sigma,
+                     double *tau_out, int *lin_iters_out);
+
+/* outer-update helpers */
+int qdev_primal_infeasibility(QpdoDev *d, double eps_prim_inf, int *is_infeasible);  /* termination.c:97-151 */
+int qdev_dual_infeasibility(QpdoDev *d, int proximal, double sigma, double tau,
+                            double eps_dual_inf, int *is_infeasible);                /* termination.c:156-216 */
+int qdev_shift_estimates(QpdoDev *d);                                                /* qpdo.c:396-397 */
+/* update_mu (iteration.c:127-168): returns number of changed rows; if !reset_decided_by_sigma and
+ * 0 < n_changed <= 25 the caller invokes qdev_mu_changed_update. */
+int qdev_update_mu(QpdoDev *d, double eps_abs, double theta, double delta, double mu_min,
+                   double isq_mu_min, int *n_changed);
+int qdev_mu_changed_update(QpdoDev *d);                                              /* cholmod_interface.c:77-93 */
+int qdev_update_sigma(QpdoDev *d, double sigma_new, double sigma_old);               /* iteration.c:173-180 */
+int qdev_save_res_prim(QpdoDev *d);                                                  /* qpdo.c:425 */
+
+/* objective (iteration.c:185-221) and final solution (termination.c:82-92) */
+int qdev_objective(QpdoDev *d, int proximal, double sigma, double c_const, double *objective);
+int qdev_store_solution(QpdoDev *d, double *sol_x, double *sol_y, double *x, double *y,
+                        double *dx, double *dy);
+/* qdpo_update_q support (qpdo.c:549-586): Qx -= sigma x ; returns ||q + cinv Qx||inf etc. on host */
+int qdev_download_vec(QpdoDev *d, int which, double *dst);   /* 0 x, 1 Qx, 2 y */
+int qdev_upload_vec(QpdoDev *d, int which, const double *src);
+
+/* configuration (environment-driven in the driver) */
+int qdev_configure(QpdoDev *d, int linsolve /*0 pcg,1 dense,-1 auto*/, double pcg_tol, int pcg_maxit);
+int qdev_get_stats(QpdoDev *d, QdevStats *out);
+int qdev_reset_stats(QpdoDev *d);
+/* HIP-event average of the A' SpMV sampled once per PCG batch during the last solve */
+int qdev_get_spmv_sample(QpdoDev *d, double *avg_seconds, long *samples);
+
+/* micro-benchmark of the dominant kernel on the workspace's own matrices, timed with HIP
+ * events on the backend stream.  which: 0 A (CSR m x n), 1 A' (CSR n x m), 2 Q.
+ * Returns average seconds per launch and the algorithmic bytes of one launch. */
+int qdev_bench_spmv(QpdoDev *d, int which, int reps, double *avg_seconds, double *alg_bytes);
+/* standalone SpMV for parity tests: y = M v */
+int qdev_spmv(QpdoDev *d, int which, const double *v_host, double *y_host);
+/* standalone piecewise-affine linesearch for parity tests (2m entries) */
+int qdev_linesearch(QpdoDev *d, double eta, double beta, const double *delta, const double *alpha,
+                    double *tau);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

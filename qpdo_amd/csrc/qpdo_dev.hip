@@ -1,0 +1,1603 @@
+// qpdo_dev.hip -- HIP backend for gfx950 (MI355X, CDNA4): every per-iteration
+// operation of the reference solver's hot path as hand-written kernels.
+//
+// State is resident in HBM for the lifetime of the workspace; the host driver
+// (qpdo_api.c) only sees a 200-byte control block per pass.  Matrices are held
+// gather-style: CSR(A) for A*x, CSR(A') (= the caller's CSC of A) for A'*y and a
+// full symmetric CSR(Q) for Q*x, so no product needs atomics and every result is
+// reproducible run to run.  Elementwise arithmetic keeps the reference's
+// operation order and the file is compiled with -ffp-contract=off, so vector
+// kernels are bit-identical to the CPU oracle; only reductions (dot products,
+// row sums) differ in summation order.
+//
+// Wave = 64 lanes throughout.  No CUDA compatibility paths.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "qpdo_dev.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define QPDO_INFTY_D 1e20
+static const int BLK = 256;        // threads per block: 4 waves
+static const int PGRID = 1024;     // max blocks of any kernel that emits per-block partial sums
+static const u64 KEY_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
+
+static thread_local char g_err[256] = "";
+static int set_err(hipError_t e, const char *what, int line) {
+    snprintf(g_err, sizeof(g_err), "%s (line %d): %s", what, line, hipGetErrorString(e));
+    return (int)e ? (int)e : -1;
+}
+#define HIPCHK(call)                                              \
+    do {                                                          \
+        hipError_t e__ = (call);                                  \
+        if (e__ != hipSuccess) return set_err(e__, #call, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// control block: everything the host reads back per pass
+// ------------------------------------------------------------------------------------------------
+enum { N_PRIM = 0, N_DUAL, N_PRIM_IN, N_DUAL_IN, N_A, N_B, N_C, N_D, N_COUNT };
+enum { C_ACTIVE = 0, C_ENTER, C_LEAVE, C_NL, C_KSTAR, C_MUCH, C_VIOL, C_PCG_DONE, C_PCG_IT, C_COUNT = 12 };
+enum { V_TAU = 0, V_A0, V_B0, V_RZ, V_BNORM, V_OOB, V_QDX, V_OBJ, V_F, V_RR, V_COUNT = 16 };
+struct Ctrl {
+    u64 nrm[N_COUNT];      // non-negative doubles as bit patterns: atomicMax is exact and order free
+    int cnt[C_COUNT];
+    double val[V_COUNT];
+};
+
+// partial-sum slots (each PGRID doubles)
+enum { P_ETA_M = 0, P_BETA_M, P_A0, P_B0, P_DXQDX, P_DXDF, P_PKP, P_RZ, P_RR, P_OOB, P_QDX, P_OBJ, P_F1, P_F2, P_COUNT };
+
+struct DevCsr {
+    int nrows = 0, ncols = 0;
+    long long nnz = 0;
+    int *rp = nullptr, *ci = nullptr;
+    double *val = nullptr;
+    int tpr = 64;            // threads cooperating on one row
+    double alg_bytes() const { return 12.0 * (double)nnz + 4.0 * (nrows + 1) + 8.0 * nrows + 8.0 * ncols; }
+};
+
+struct QpdoDev {
+    int device = 0, n = 0, m = 0;
+    hipStream_t stream = nullptr;
+    DevCsr Ar, At, Qf;
+    // n-vectors
+    double *x, *xbar, *Qx, *Aty, *q, *df, *res_dual, *res_dual_in, *rhs, *dx, *Qdx, *Atdy, *D, *Dinv;
+    double *pc_r, *pc_z, *pc_p, *pc_Kp, *pc_diag, *tmp_n;
+    // m-vectors
+    double *y, *ybar, *Ax, *l, *u, *mu, *isq, *w, *res_prim, *res_prim_old, *res_prim_in, *dy, *Adx, *d, *E,
+        *Einv, *pc_t, *at_scale, *tmp_m;
+    int *active, *active_old, *mu_changed;
+    // 2m linesearch
+    double *ls_delta, *ls_alpha, *ls_pa, *ls_pb;
+    u64 *ls_key[2];
+    u32 *ls_idx[2];
+    int *rs_hist; int rs_nblocks = 0;
+    double *ls_bt;           // block totals (2 * nblk)
+    int ls_nblk = 0;
+    // control
+    Ctrl *ctrl = nullptr;    // device
+    Ctrl *hctrl = nullptr;   // pinned host
+    double *part = nullptr;  // P_COUNT * PGRID
+    // scaling
+    int scaled = 0; double sc_c = 1.0, sc_cinv = 1.0;
+    // factor state
+    double sigma_f = 0.0;
+    // config
+    int linsolve = 0; double pcg_tol = 1e-12; int pcg_maxit = 100000; int pcg_batch = 16;
+    // stats
+    QdevStats st{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double ev_spmv_ms = 0.0; long long ev_spmv_n = 0;
+    std::vector<void *> allocs;
+};
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// sum over the block; result valid in every thread.  sm: >= 4 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double *sm) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sm[w] = v;
+    __syncthreads();
+    double t = sm[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); i++) t += sm[i];
+    return t;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_down(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+// max over block of non-negative values then one atomicMax on the bit pattern (exact).
+__device__ __forceinline__ void block_max_to(double v, u64 *dst, double *sm) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sm[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sm[0];
+        for (int i = 1; i < (int)(blockDim.x >> 6); i++) t = sm[i] > t ? sm[i] : t;
+        if (t > 0.0) atomicMax(dst, (u64)__double_as_longlong(t));
+    }
+}
+// reference c_absval / '>' semantics: a NaN never replaces the running maximum (lin_alg.c:107-140)
+__device__ __forceinline__ double absmax_acc(double mx, double a) {
+    double s = a < 0 ? -a : a;
+    return s > mx ? s : mx;
+}
+__device__ __forceinline__ double mid3(double a, double lo, double hi) {   // lin_alg.c:163-168
+    double t = a < hi ? a : hi;
+    return lo > t ? lo : t;
+}
+// every block re-reduces `cnt` per-block partial sums in a fixed order (deterministic)
+__device__ __forceinline__ double reduce_partials(const double *p, int cnt, double *sm) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) s += p[i];
+    return block_sum(s, sm);
+}
+__device__ __forceinline__ int block_sum_int(int v, int *sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sm[w] = v;
+    __syncthreads();
+    int t = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += sm[i];
+    return t;
+}
+
+static inline int vgrid(long long len) {
+    long long g = (len + BLK - 1) / BLK;
+    if (g < 1) g = 1;
+    if (g > PGRID) g = PGRID;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SpMV: y = M x, CSR, TPR lanes cooperate on a row, shuffle reduction inside the lane group.
+// The epilogue functor receives the row sum in lane 0 of the group and may fuse the vector work
+// that follows the product in the reference (S1/S2 + V1, N5, L1 of SURVEY section 8).
+// ------------------------------------------------------------------------------------------------
+template <int TPR>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) v += __shfl_down(v, o, TPR);
+    return v;
+}
+
+template <int TPR, class Epi>
+__global__ __launch_bounds__(256) void k_spmv(int nrows, const int *__restrict__ rp, const int *__restrict__ ci,
+                                              const double *__restrict__ val, const double *__restrict__ x, Epi epi) {
+    __shared__ double sm[8];
+    const int lane = threadIdx.x % TPR;
+    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
+    const int ngroups = gridDim.x * (BLK / TPR);
+    for (int row = group; row < nrows; row += ngroups) {
+        double s = 0.0;
+        if (!epi.skip(row)) {
+            const int beg = rp[row], end = rp[row + 1];
+            double s0 = 0.0, s1 = 0.0;
+            int k = beg + lane;
+            for (; k + TPR < end; k += 2 * TPR) {
+                const double v0 = val[k], v1 = val[k + TPR];
+                const int c0 = ci[k], c1 = ci[k + TPR];
+                s0 += v0 * x[c0];
+                s1 += v1 * x[c1];
+            }
+            if (k < end) s0 += val[k] * x[ci[k]];
+            s = group_sum<TPR>(s0 + s1);
+        }
+        if (lane == 0) epi.row(row, s);
+    }
+    epi.finish(sm);
+}
+
+struct EpiStore {                          // y = M x
+    double *y;
+    __device__ bool skip(int) const { return false; }
+    __device__ void row(int r, double s) { y[r] = s; }
+    __device__ void finish(double *) {}
+};
+struct EpiRhs {                            // newton.c:42-45: Atdy = A' t ; rhs = -res_dual_in - Atdy
+    const double *rdi; double *atdy, *rhs;
+    __device__ bool skip(int) const { return false; }
+    __device__ void row(int r, double s) { atdy[r] = s; rhs[r] = -rdi[r] - s; }
+    __device__ void finish(double *) {}
+};
+struct EpiQdx {                            // newton.c:52-55 + the two n-dots of linesearch.c:19-25
+    const double *dx, *df; double sigma; int prox; double *Qdx, *p_dxQdx, *p_dxdf;
+    double a1 = 0.0, a2 = 0.0;
+    __device__ bool skip(int) const { return false; }
+    __device__ void row(int r, double s) {
+        double v = prox ? s + sigma * dx[r] : s;
+        Qdx[r] = v; a1 += dx[r] * v; a2 += dx[r] * df[r];
+    }
+    __device__ void finish(double *sm) {
+        double t1 = block_sum(a1, sm), t2 = block_sum(a2, sm + 4);
+        if (threadIdx.x == 0) { p_dxQdx[blockIdx.x] = t1; p_dxdf[blockIdx.x] = t2; }
+    }
+};
+struct EpiQpure {                          // qpdo.c:385: Qdx = Q dx (no sigma), warm start Qx
+    const double *xv; double sigma; int prox; double *out;
+    __device__ bool skip(int) const { return false; }
+    __device__ void row(int r, double s) { out[r] = prox ? s + sigma * xv[r] : s; }
+    __device__ void finish(double *) {}
+};
+// A*dx with the m-side of newton.c:57-63 and linesearch.c:13-40,82-120 fused behind it
+struct EpiAdxLs {
+    int m;
+    const double *mu, *isq, *w, *l, *u, *y; const int *active; int *active_old;
+    double *Adx, *dy, *delta, *alpha; u64 *key; u32 *idx;
+    double *p_eta, *p_beta, *p_a0, *p_b0; Ctrl *ctrl;
+    double e = 0.0, b = 0.0, a0 = 0.0, b0 = 0.0; int nL = 0;
+    __device__ bool skip(int) const { return false; }
+    __device__ void cand(int i, double dl, double al) {
+        delta[i] = dl; alpha[i] = al;
+        const double t = al / dl;
+        const bool L = t > 0, P = dl > 0;
+        key[i] = L ? (u64)__double_as_longlong(t) : KEY_SENTINEL;
+        idx[i] = (u32)i;
+        if (L) nL++;
+        if (L != P) { a0 += dl * dl; b0 += dl * al; }
+    }
+    __device__ void row(int r, double s) {
+        Adx[r] = s;
+        const int act = active[r];
+        double dyr = dy[r];
+        if (act) dyr += s / mu[r];
+        dy[r] = dyr;
+        active_old[r] = act;                       // newton.c:69
+        double sv = dyr * mu[r]; sv = sv * 0.5;    // linesearch.c:14-15
+        e += dyr * sv; b += y[r] * sv;
+        double c0 = s - sv; c0 = c0 * isq[r];      // linesearch.c:27-28
+        const double dlo = c0 * -1.0;
+        const double alo = (w[r] - l[r]) * isq[r];
+        const double ahi = (u[r] - w[r]) * isq[r];
+        cand(r, dlo, alo);
+        cand(r + m, c0, ahi);
+    }
+    __device__ void finish(double *sm) {
+        double t1 = block_sum(e, sm), t2 = block_sum(b, sm + 4);
+        double t3 = block_sum(a0, sm), t4 = block_sum(b0, sm + 4);
+        int tn = block_sum_int(nL, (int *)sm);
+        if (threadIdx.x == 0) {
+            p_eta[blockIdx.x] = t1; p_beta[blockIdx.x] = t2; p_a0[blockIdx.x] = t3; p_b0[blockIdx.x] = t4;
+            if (tn) atomicAdd(&ctrl->cnt[C_NL], tn);
+        }
+    }
+};
+struct EpiPcgA {                           // t = d .* (A p); rows with zero weight are not read
+    const double *d; double *t; const int *done;
+    __device__ bool skip(int r) const { return d[r] == 0.0; }
+    __device__ void row(int r, double s) { t[r] = d[r] * s; }
+    __device__ void finish(double *) {}
+};
+struct EpiPcgQ {                           // Kp = Q p + sigma_f p
+    const double *p; double sigma_f; double *Kp;
+    __device__ bool skip(int) const { return false; }
+    __device__ void row(int r, double s) { Kp[r] = s + sigma_f * p[r]; }
+    __device__ void finish(double *) {}
+};
+struct EpiPcgAt {                          // Kp += A' t ; partial p.Kp
+    const double *p; double *Kp, *p_pKp; double acc = 0.0;
+    __device__ bool skip(int) const { return false; }
+    __device__ void row(int r, double s) { double v = Kp[r] + s; Kp[r] = v; acc += p[r] * v; }
+    __device__ void finish(double *sm) {
+        double t = block_sum(acc, sm);
+        if (threadIdx.x == 0) p_pKp[blockIdx.x] = t;
+    }
+};
+
+static inline int spmv_grid(const DevCsr &M, int tpr, bool partials) {
+    long long groups_per_block = BLK / tpr;
+    long long g = (M.nrows + groups_per_block - 1) / groups_per_block;
+    long long cap = partials ? PGRID : 4096;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+template <class Epi>
+static void launch_spmv(QpdoDev *d, const DevCsr &M, const double *x, Epi epi, bool partials) {
+    const int g = spmv_grid(M, M.tpr, partials);
+    switch (M.tpr) {
+        case 4:  hipLaunchKernelGGL((k_spmv<4, Epi>),  dim3(g), dim3(BLK), 0, d->stream, M.nrows, M.rp, M.ci, M.val, x, epi); break;
+        case 8:  hipLaunchKernelGGL((k_spmv<8, Epi>),  dim3(g), dim3(BLK), 0, d->stream, M.nrows, M.rp, M.ci, M.val, x, epi); break;
+        case 16: hipLaunchKernelGGL((k_spmv<16, Epi>), dim3(g), dim3(BLK), 0, d->stream, M.nrows, M.rp, M.ci, M.val, x, epi); break;
+        case 32: hipLaunchKernelGGL((k_spmv<32, Epi>), dim3(g), dim3(BLK), 0, d->stream, M.nrows, M.rp, M.ci, M.val, x, epi); break;
+        default: hipLaunchKernelGGL((k_spmv<64, Epi>), dim3(g), dim3(BLK), 0, d->stream, M.nrows, M.rp, M.ci, M.val, x, epi); break;
+    }
+    d->st.spmv_calls++;
+    d->st.spmv_bytes += (int64_t)M.alg_bytes();
+}
+// number of blocks a partial-emitting spmv launch uses (consumers need it)
+static inline int spmv_pgrid(const DevCsr &M) { return spmv_grid(M, M.tpr, true); }
+
+// PCG variant: identical body, but every thread leaves at once when the solver has converged.
+template <int TPR, class Epi>
+__global__ __launch_bounds__(256) void k_spmv_pcg(const int *__restrict__ done, int nrows, const int *__restrict__ rp,
+                                                  const int *__restrict__ ci, const double *__restrict__ val,
+                                                  const double *__restrict__ x, Epi epi) {
+    __shared__ double sm[8];
+    if (*done) return;
+    const int lane = threadIdx.x % TPR;
+    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
+    const int ngroups = gridDim.x * (BLK / TPR);
+    for (int row = group; row < nrows; row += ngroups) {
+        double s = 0.0;
+        if (!epi.skip(row)) {
+            const int beg = rp[row], end = rp[row + 1];
+            double s0 = 0.0, s1 = 0.0;
+            int k = beg + lane;
+            for (; k + TPR < end; k += 2 * TPR) {
+                const double v0 = val[k], v1 = val[k + TPR];
+                const int c0 = ci[k], c1 = ci[k + TPR];
+                s0 += v0 * x[c0];
+                s1 += v1 * x[c1];
+            }
+            if (k < end) s0 += val[k] * x[ci[k]];
+            s = group_sum<TPR>(s0 + s1);
+        }
+        if (lane == 0) epi.row(row, s);
+    }
+    epi.finish(sm);
+}
+template <class Epi>
+static void launch_spmv_pcg(QpdoDev *d, const DevCsr &M, const double *x, Epi epi, bool partials) {
+    const int g = spmv_grid(M, M.tpr, partials);
+    const int *done = &d->ctrl->cnt[C_PCG_DONE];
+    switch (M.tpr) {
+        case 4:  hipLaunchKernelGGL((k_spmv_pcg<4, Epi>),  dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
+        case 8:  hipLaunchKernelGGL((k_spmv_pcg<8, Epi>),  dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
+        case 16: hipLaunchKernelGGL((k_spmv_pcg<16, Epi>), dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
+        case 32: hipLaunchKernelGGL((k_spmv_pcg<32, Epi>), dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
+        default: hipLaunchKernelGGL((k_spmv_pcg<64, Epi>), dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
+    }
+    d->st.spmv_calls++;
+    d->st.spmv_bytes += (int64_t)M.alg_bytes();
+}
+
+// row-wise max |a_ij| (Ruiz norms, cholmod_interface.c:162-199) -- one lane group per row
+template <int TPR>
+__global__ __launch_bounds__(256) void k_row_absmax(int nrows, const int *__restrict__ rp, const double *__restrict__ val,
+                                                    double *__restrict__ out) {
+    const int lane = threadIdx.x % TPR;
+    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
+    const int ngroups = gridDim.x * (BLK / TPR);
+    for (int row = group; row < nrows; row += ngroups) {
+        double mx = 0.0;
+        for (int k = rp[row] + lane; k < rp[row + 1]; k += TPR) mx = absmax_acc(mx, val[k]);
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1) { double t = __shfl_down(mx, o, TPR); mx = t > mx ? t : mx; }
+        if (lane == 0) out[row] = mx;
+    }
+}
+// val[k] = (val[k] * rs[row or col]) * cs[...]: ROW scale then COL scale (scaling.c:56-57)
+template <int TPR>
+__global__ __launch_bounds__(256) void k_scale_rows_cols(int nrows, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                         double *__restrict__ val, const double *__restrict__ first_by_row,
+                                                         const double *__restrict__ first_by_col,
+                                                         const double *__restrict__ second_by_row,
+                                                         const double *__restrict__ second_by_col) {
+    const int lane = threadIdx.x % TPR;
+    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
+    const int ngroups = gridDim.x * (BLK / TPR);
+    for (int row = group; row < nrows; row += ngroups) {
+        for (int k = rp[row] + lane; k < rp[row + 1]; k += TPR) {
+            double v = val[k];
+            v = v * (first_by_row ? first_by_row[row] : first_by_col[ci[k]]);
+            v = v * (second_by_row ? second_by_row[row] : second_by_col[ci[k]]);
+            val[k] = v;
+        }
+    }
+}
+// Q <- D Q D: val *= (D[col] * D[row]) for a stored lower entry (row i, col j): t = s[j]; x *= t*s[i]
+template <int TPR>
+__global__ __launch_bounds__(256) void k_scale_sym(int nrows, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                   double *__restrict__ val, const double *__restrict__ D) {
+    const int lane = threadIdx.x % TPR;
+    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
+    const int ngroups = gridDim.x * (BLK / TPR);
+    for (int row = group; row < nrows; row += ngroups) {
+        for (int k = rp[row] + lane; k < rp[row + 1]; k += TPR) {
+            const int c = ci[k];
+            // lower entry (i>=j) is stored as (row=i,col=j): t = D[j] * D[i]; its mirror computes the same product
+            const double t = row >= c ? D[c] * D[row] : D[row] * D[c];
+            val[k] *= t;
+        }
+    }
+}
+__global__ void k_scale_vals(long long nnz, double *__restrict__ val, double f) {
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) val[k] *= f;
+}
+// Jacobi diagonal: diag_j = Q_jj + sigma_f + sum_i A_ij^2 d_i  (row j of CSR(A'))
+template <int TPR>
+__global__ __launch_bounds__(256) void k_jacobi_diag(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                     const double *__restrict__ val, const double *__restrict__ dw,
+                                                     const double *__restrict__ qdiag, double sigma_f, double *__restrict__ out) {
+    const int lane = threadIdx.x % TPR;
+    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
+    const int ngroups = gridDim.x * (BLK / TPR);
+    for (int row = group; row < n; row += ngroups) {
+        double s = 0.0;
+        for (int k = rp[row] + lane; k < rp[row + 1]; k += TPR) { double v = val[k]; s += v * v * dw[ci[k]]; }
+        s = group_sum<TPR>(s);
+        if (lane == 0) out[row] = qdiag[row] + sigma_f + s;
+    }
+}
+__global__ void k_extract_diag(int n, const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
+                               double *__restrict__ out) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        double dg = 0.0;
+        for (int k = rp[r]; k < rp[r + 1]; k++) if (ci[k] == r) dg += val[k];
+        out[r] = dg;
+    }
+}
+
+#define DISPATCH_TPR(M, KERNEL, GRID, ...)                                                                  \
+    switch ((M).tpr) {                                                                                      \
+        case 4:  hipLaunchKernelGGL((KERNEL<4>),  dim3(GRID), dim3(BLK), 0, d->stream, __VA_ARGS__); break; \
+        case 8:  hipLaunchKernelGGL((KERNEL<8>),  dim3(GRID), dim3(BLK), 0, d->stream, __VA_ARGS__); break; \
+        case 16: hipLaunchKernelGGL((KERNEL<16>), dim3(GRID), dim3(BLK), 0, d->stream, __VA_ARGS__); break; \
+        case 32: hipLaunchKernelGGL((KERNEL<32>), dim3(GRID), dim3(BLK), 0, d->stream, __VA_ARGS__); break; \
+        default: hipLaunchKernelGGL((KERNEL<64>), dim3(GRID), dim3(BLK), 0, d->stream, __VA_ARGS__); break; \
+    }
+
+// ------------------------------------------------------------------------------------------------
+// vector kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void k_ctrl_clear_pass(Ctrl *c) {
+    const int t = threadIdx.x;
+    if (t < 4) c->nrm[t] = 0ull;
+    if (t >= 8 && t < 11) c->cnt[t - 8] = 0;
+}
+__global__ void k_ctrl_clear_aux(Ctrl *c) {
+    const int t = threadIdx.x;
+    if (t < 4) c->nrm[N_A + t] = 0ull;
+    if (t == 4) c->cnt[C_MUCH] = 0;
+    if (t == 5) c->cnt[C_VIOL] = 0;
+}
+
+// m-side of iteration.c:30-47,65-81, termination.c:39-41,62-64 and newton.c:96-126 in one pass
+__global__ __launch_bounds__(256) void k_resid_m(int m, int scaled, double cinv, const double *__restrict__ Ax,
+                                                 const double *__restrict__ y, const double *__restrict__ ybar,
+                                                 const double *__restrict__ mu, const double *__restrict__ l,
+                                                 const double *__restrict__ u, const double *__restrict__ E,
+                                                 const double *__restrict__ Einv, double *__restrict__ res_prim,
+                                                 double *__restrict__ w, double *__restrict__ res_prim_in,
+                                                 int *__restrict__ active, const int *__restrict__ active_old, Ctrl *ctrl) {
+    __shared__ double sm[8];
+    double mx1 = 0.0, mx2 = 0.0; int na = 0, ne = 0, nl = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const double ax = Ax[i], yi = y[i], li = l[i], ui = u[i], mui = mu[i], yb = ybar[i];
+        double t;
+        if (scaled) { t = E[i] * yi; t = t * cinv; t = E[i] * t; t = ax + t; }
+        else t = ax + yi;
+        const double z = mid3(t, li, ui);
+        const double rp = ax - z;
+        res_prim[i] = rp;
+        const double wi = ax + mui * (yb - 0.5 * yi);
+        w[i] = wi;
+        const double zin = mid3(wi, li, ui);
+        const double rpi = ax + mui * (yb - yi) - zin;
+        res_prim_in[i] = rpi;
+        const int act = (wi <= li) || (wi >= ui);
+        active[i] = act;
+        const int old = active_old[i];
+        na += act; ne += (act && !old); nl += (!act && old);
+        mx1 = absmax_acc(mx1, scaled ? Einv[i] * rp : rp);
+        mx2 = absmax_acc(mx2, scaled ? Einv[i] * rpi : rpi);
+    }
+    block_max_to(mx1, &ctrl->nrm[N_PRIM], sm);
+    block_max_to(mx2, &ctrl->nrm[N_PRIM_IN], sm + 4);
+    int ta = block_sum_int(na, (int *)sm), te = block_sum_int(ne, (int *)sm), tl = block_sum_int(nl, (int *)sm);
+    if (threadIdx.x == 0) {
+        if (ta) atomicAdd(&ctrl->cnt[C_ACTIVE], ta);
+        if (te) atomicAdd(&ctrl->cnt[C_ENTER], te);
+        if (tl) atomicAdd(&ctrl->cnt[C_LEAVE], tl);
+    }
+}
+// n-side of iteration.c:48-59,82-92 and termination.c:43-45,69-72
+__global__ __launch_bounds__(256) void k_resid_n(int n, int scaled, int prox, double sigma, const double *__restrict__ Qx,
+                                                 const double *__restrict__ q, const double *__restrict__ x,
+                                                 const double *__restrict__ xbar, const double *__restrict__ Aty,
+                                                 const double *__restrict__ Dinv, double *__restrict__ df,
+                                                 double *__restrict__ res_dual, double *__restrict__ res_dual_in, Ctrl *ctrl) {
+    __shared__ double sm[8];
+    double mx1 = 0.0, mx2 = 0.0;
+    const double ns = -sigma;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const double df0 = Qx[j] + q[j], aty = Aty[j];
+        double rd, dfi;
+        if (prox) { rd = df0 + ns * x[j]; rd = rd + aty; dfi = df0 + ns * xbar[j]; }
+        else { rd = df0 + aty; dfi = df0; }
+        const double rdi = dfi + aty;
+        df[j] = dfi; res_dual[j] = rd; res_dual_in[j] = rdi;
+        mx1 = absmax_acc(mx1, scaled ? Dinv[j] * rd : rd);
+        mx2 = absmax_acc(mx2, scaled ? Dinv[j] * rdi : rdi);
+    }
+    block_max_to(mx1, &ctrl->nrm[N_DUAL], sm);
+    block_max_to(mx2, &ctrl->nrm[N_DUAL_IN], sm + 4);
+}
+
+// factor-state weights d (cholmod_interface.c:35-72 as rules on d) + t = (I+P) res_prim_in ./ mu (newton.c:37-40)
+__global__ void k_newton_prep(int m, int branch, const int *__restrict__ active, const int *__restrict__ active_old,
+                              const double *__restrict__ isq, const double *__restrict__ mu,
+                              const double *__restrict__ res_prim_in, double *__restrict__ d, double *__restrict__ dy) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const int act = active[i], old = active_old[i];
+        const double wgt = isq[i] * isq[i];
+        if (branch == 0) d[i] = act ? wgt : 0.0;
+        else if (branch == 1) { if (act && !old) d[i] += wgt; else if (!act && old) d[i] -= wgt; }
+        else d[i] = 0.0;
+        double t = res_prim_in[i] / mu[i];
+        if (!act) t *= 2;
+        dy[i] = t;
+    }
+}
+
+// iteration.c:19-24: five axpys with tau read from the control block
+__global__ void k_axpy5(int n, int m, const Ctrl *__restrict__ ctrl, double *__restrict__ x, const double *__restrict__ dx,
+                        double *__restrict__ Qx, const double *__restrict__ Qdx, double *__restrict__ Aty,
+                        const double *__restrict__ Atdy, double *__restrict__ y, const double *__restrict__ dy,
+                        double *__restrict__ Ax, const double *__restrict__ Adx) {
+    const double tau = ctrl->val[V_TAU];
+    const int tot = n > m ? n : m;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += gridDim.x * blockDim.x) {
+        if (i < n) { x[i] = x[i] + tau * dx[i]; Qx[i] = Qx[i] + tau * Qdx[i]; Aty[i] = Aty[i] + tau * Atdy[i]; }
+        if (i < m) { y[i] = y[i] + tau * dy[i]; Ax[i] = Ax[i] + tau * Adx[i]; }
+    }
+}
+__global__ void k_sub(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ c) {  // c = a + (-1) b
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c[i] = a[i] - b[i];
+}
+__global__ void k_axpy(int n, double sc, const double *__restrict__ b, double *__restrict__ a) {   // a = a + sc b
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = a[i] + sc * b[i];
+}
+__global__ void k_mul(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ c) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c[i] = a[i] * b[i];
+}
+__global__ void k_scal(int n, double sc, double *__restrict__ a) {   // a *= sc (lin_alg.c:45-50)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] *= sc;
+}
+__global__ void k_fill(int n, double v, double *__restrict__ a) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = v;
+}
+__global__ void k_fill_int(int n, int v, int *__restrict__ a) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = v;
+}
+// Ruiz: limit (<1e-9 -> 1), sqrt, reciprocal, accumulate into total (scaling.c:44-61)
+__global__ void k_ruiz_factor(int n, double *__restrict__ t, double *__restrict__ total) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double v = t[i];
+        v = v < 1e-9 ? 1.0 : v;
+        v = sqrt(v);
+        v = 1.0 / v;
+        t[i] = v;
+        total[i] = total[i] * v;
+    }
+}
+__global__ void k_recip(int n, const double *__restrict__ a, double *__restrict__ b) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) b[i] = 1.0 / a[i];
+}
+// max |a + sc*b| into ctrl->nrm[slot]
+__global__ __launch_bounds__(256) void k_absmax_axpy(int n, const double *__restrict__ a, const double *__restrict__ b, double sc,
+                                                     Ctrl *ctrl, int slot) {
+    __shared__ double sm[8];
+    double mx = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        mx = absmax_acc(mx, b ? a[i] + sc * b[i] : a[i]);
+    block_max_to(mx, &ctrl->nrm[slot], sm);
+}
+__global__ __launch_bounds__(256) void k_absmax_mul(int n, const double *__restrict__ a, const double *__restrict__ b,
+                                                    Ctrl *ctrl, int slot) {
+    __shared__ double sm[8];
+    double mx = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        mx = absmax_acc(mx, b ? a[i] * b[i] : a[i]);
+    block_max_to(mx, &ctrl->nrm[slot], sm);
+}
+
+// warm start pieces (qpdo.c:238-279)
+__global__ void k_ws_x(int n, int scaled, const double *__restrict__ xin, const double *__restrict__ Dinv,
+                       double *__restrict__ x, double *__restrict__ xbar) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double v = xin[i];
+        if (scaled) v = v * Dinv[i];
+        x[i] = v; xbar[i] = v;
+    }
+}
+__global__ void k_ws_y(int m, int scaled, double c, const double *__restrict__ yin, const double *__restrict__ Einv,
+                       double *__restrict__ y, double *__restrict__ ybar) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        double v = yin[i];
+        if (scaled) { v = v * Einv[i]; v = v * c; }
+        y[i] = v; ybar[i] = v;
+    }
+}
+// partial dots for f = 0.5 x'Qx + q'x (iteration.c:102) and the objective (iteration.c:185-221)
+__global__ __launch_bounds__(256) void k_dots_f(int n, const double *__restrict__ x, const double *__restrict__ Qx,
+                                                const double *__restrict__ q, double *__restrict__ p1, double *__restrict__ p2) {
+    __shared__ double sm[8];
+    double a = 0.0, b = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { a += x[i] * Qx[i]; b += q[i] * x[i]; }
+    double ta = block_sum(a, sm), tb = block_sum(b, sm + 4);
+    if (threadIdx.x == 0) { p1[blockIdx.x] = ta; p2[blockIdx.x] = tb; }
+}
+__global__ __launch_bounds__(256) void k_objective(int n, int prox, double sigma, const double *__restrict__ x,
+                                                   const double *__restrict__ Qx, const double *__restrict__ q,
+                                                   double *__restrict__ p) {
+    __shared__ double sm[8];
+    double a = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        a += prox ? (0.5 * (Qx[i] - x[i] * sigma) + q[i]) * x[i] : (0.5 * Qx[i] + q[i]) * x[i];
+    double t = block_sum(a, sm);
+    if (threadIdx.x == 0) p[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void k_reduce_to_ctrl(const double *__restrict__ p, int cnt, Ctrl *ctrl, int slot) {
+    __shared__ double sm[8];
+    double t = reduce_partials(p, cnt, sm);
+    if (threadIdx.x == 0) ctrl->val[slot] = t;
+}
+// iteration.c:98-122
+__global__ __launch_bounds__(256) void k_init_mu(int m, const double *__restrict__ p1, const double *__restrict__ p2, int pcnt,
+                                                 const double *__restrict__ Ax, const double *__restrict__ l,
+                                                 const double *__restrict__ u, double *__restrict__ mu, double *__restrict__ isq) {
+    __shared__ double sm[8];
+    const double xQx = reduce_partials(p1, pcnt, sm), qx = reduce_partials(p2, pcnt, sm + 4);
+    const double f = 0.5 * xQx + qx;
+    const double af = f < 0 ? -f : f;
+    const double den = 1 > af ? 1 : af;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const double ax = Ax[i];
+        const double r = ax - mid3(ax, l[i], u[i]);
+        double v = 0.5 * r * r;
+        v = 1 > v ? 1 : v;
+        v = 0.1 * v / den;
+        v = 1e3 < v ? 1e3 : v;
+        v = 1e-3 > v ? 1e-3 : v;
+        mu[i] = v;
+        double s = sqrt(v);
+        isq[i] = 1.0 / s;
+    }
+}
+
+// ---- infeasibility certificates (termination.c:97-216) -----------------------------------------
+// primal, stage 2: Atdy <- Dinv .* Atdy (n-part) ; oob partials (m-part)
+__global__ __launch_bounds__(256) void k_pinf_n(int n, int scaled, const double *__restrict__ Dinv, double *__restrict__ Atdy,
+                                                Ctrl *ctrl) {
+    __shared__ double sm[8];
+    double mx = 0.0;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        double v = Atdy[j];
+        if (scaled) { v = Dinv[j] * v; Atdy[j] = v; }
+        mx = absmax_acc(mx, v);
+    }
+    block_max_to(mx, &ctrl->nrm[N_B], sm);
+}
+__global__ __launch_bounds__(256) void k_pinf_m(int m, int scaled, const double *__restrict__ dy, const double *__restrict__ l,
+                                                const double *__restrict__ u, const double *__restrict__ E,
+                                                double *__restrict__ part) {
+    __shared__ double sm[8];
+    double s = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const double e = scaled ? E[i] : 1.0, v = dy[i];
+        const double pos = v > 0 ? v : 0, neg = v < 0 ? v : 0;
+        s += (u[i] < e * QPDO_INFTY_D) ? u[i] * pos : 0;
+        s += (l[i] > -e * QPDO_INFTY_D) ? l[i] * neg : 0;
+    }
+    double t = block_sum(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ void k_pinf_cert(int m, double cinv, const double *__restrict__ E, double *__restrict__ dy) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        double v = dy[i] * cinv;
+        dy[i] = E[i] * v;
+    }
+}
+// dual, stage 2: Adx <- Einv .* Adx, violation flag (termination.c:185-199)
+__global__ void k_dinf_m(int m, int scaled, double eps, const double *__restrict__ Einv, const double *__restrict__ E,
+                         const double *__restrict__ l, const double *__restrict__ u, double *__restrict__ Adx, Ctrl *ctrl) {
+    int viol = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
+        double v = Adx[k];
+        const double e = scaled ? E[k] : 1.0;
+        if (scaled) { v = Einv[k] * v; Adx[k] = v; }
+        if ((u[k] < e * QPDO_INFTY_D && v >= eps) || (l[k] > -e * QPDO_INFTY_D && v <= -eps)) viol = 1;
+    }
+    if (viol) atomicOr(&ctrl->cnt[C_VIOL], 1);
+}
+// dual, stage 3: Qdx += (-sigma*tau) dx ; ||Qdx||inf ; partial q.dx
+__global__ __launch_bounds__(256) void k_dinf_n(int n, int prox, double st, const double *__restrict__ dx, const double *__restrict__ q,
+                                                double *__restrict__ Qdx, Ctrl *ctrl, double *__restrict__ part) {
+    __shared__ double sm[8];
+    double mx = 0.0, s = 0.0;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        double v = Qdx[j];
+        if (prox) { v = v + st * dx[j]; Qdx[j] = v; }
+        mx = absmax_acc(mx, v);
+        s += q[j] * dx[j];
+    }
+    block_max_to(mx, &ctrl->nrm[N_D], sm);
+    double t = block_sum(s, sm + 4);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// ---- update_mu (iteration.c:127-168) -------------------------------------------------------------
+__global__ void k_update_mu(int m, double eps_abs, double theta, double delta, double mu_min, double isq_mu_min,
+                            const Ctrl *cin, const double *__restrict__ res_prim,
+                            const double *__restrict__ res_prim_old, double *__restrict__ mu, double *__restrict__ isq,
+                            double *__restrict__ at_scale, int *__restrict__ changed, Ctrl *ctrl) {
+    const double rpn = __longlong_as_double((long long)cin->nrm[N_A]);
+    int cnt = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
+        const double rp = res_prim[k], arp = rp < 0 ? -rp : rp;
+        const double ro = res_prim_old[k], aro = ro < 0 ? -ro : ro;
+        const double thr = theta * aro;
+        int ch = 0;
+        if (arp > (eps_abs > thr ? eps_abs : thr)) {
+            const double ratio = delta * rpn / arp;
+            double mu_factor = 1.0 / (1.0 < ratio ? 1.0 : ratio);
+            const double mu_new = mu[k] / mu_factor;
+            if (mu_new >= mu_min) {
+                if (mu[k] != mu_new) ch = 1;
+                mu[k] = mu_new;
+                mu_factor = sqrt(mu_factor);
+                isq[k] = mu_factor * isq[k];
+                at_scale[k] = mu_factor;
+            } else {
+                if (mu[k] != mu_min) ch = 1;
+                mu[k] = mu_min;
+                at_scale[k] = isq_mu_min / isq[k];
+                isq[k] = isq_mu_min;
+            }
+        } else at_scale[k] = 1.0;
+        changed[k] = ch;
+        cnt += ch;
+    }
+    if (cnt) atomicAdd(&ctrl->cnt[C_MUCH], cnt);
+}
+// cholmod_interface.c:77-93 as a weight update: d_k += (isq_k * sqrt(1 - 1/s_k^2))^2 for every changed k
+__global__ void k_mu_changed_d(int m, const int *__restrict__ changed, const double *__restrict__ at_scale,
+                               const double *__restrict__ isq, double *__restrict__ d) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
+        if (changed[k]) {
+            const double s = at_scale[k];
+            const double r = sqrt(1 - 1 / (s * s));
+            const double col = isq[k] * r;
+            d[k] += col * col;
+        }
+    }
+}
+
+// ---- store_solution (termination.c:82-92) ---------------------------------------------------------
+__global__ void k_store_solution(int n, int m, int scaled, double cinv, const double *__restrict__ x, const double *__restrict__ D,
+                                 double *__restrict__ y, const double *__restrict__ E, double *__restrict__ sx,
+                                 double *__restrict__ sy) {
+    const int tot = n > m ? n : m;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += gridDim.x * blockDim.x) {
+        if (i < n) sx[i] = scaled ? x[i] * D[i] : x[i];
+        if (i < m) {
+            if (scaled) { const double v = y[i] * cinv; y[i] = v; sy[i] = v * E[i]; }
+            else sy[i] = y[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Jacobi-PCG on K = Q + sigma_f I + A' diag(d) A.  Every kernel leaves immediately once the
+// device-side `done` latch is set, so the host may launch iterations in batches and still stop
+// at exactly the iteration that met the tolerance.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pcg_init(int n, const double *__restrict__ b, const double *__restrict__ dg,
+                                                  double *__restrict__ x, double *__restrict__ r, double *__restrict__ z,
+                                                  double *__restrict__ p, double *__restrict__ p_rz, double *__restrict__ p_bb) {
+    __shared__ double sm[8];
+    double a = 0.0, c = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double bi = b[i], zi = bi / dg[i];
+        x[i] = 0.0; r[i] = bi; z[i] = zi; p[i] = zi;
+        a += bi * zi; c += bi * bi;
+    }
+    double ta = block_sum(a, sm), tc = block_sum(c, sm + 4);
+    if (threadIdx.x == 0) { p_rz[blockIdx.x] = ta; p_bb[blockIdx.x] = tc; }
+}
+__global__ __launch_bounds__(256) void k_pcg_init2(const double *__restrict__ p_rz, const double *__restrict__ p_bb, int cnt, Ctrl *ctrl) {
+    __shared__ double sm[8];
+    double rz = reduce_partials(p_rz, cnt, sm), bb = reduce_partials(p_bb, cnt, sm + 4);
+    if (threadIdx.x == 0) {
+        ctrl->val[V_RZ] = rz; ctrl->val[V_BNORM] = sqrt(bb);
+        ctrl->cnt[C_PCG_DONE] = (bb == 0.0) ? 1 : 0;
+        ctrl->cnt[C_PCG_IT] = 0;
+    }
+}
+// x += alpha p ; r -= alpha Kp ; z = r/diag ; partial r.z, r.r
+__global__ __launch_bounds__(256) void k_pcg_update(int n, const Ctrl *__restrict__ ctrl, const double *__restrict__ p_pKp, int pcnt,
+                                                    const double *__restrict__ p, const double *__restrict__ Kp,
+                                                    const double *__restrict__ dg, double *__restrict__ x, double *__restrict__ r,
+                                                    double *__restrict__ z, double *__restrict__ p_rz, double *__restrict__ p_rr) {
+    __shared__ double sm[8];
+    if (ctrl->cnt[C_PCG_DONE]) return;
+    const double pKp = reduce_partials(p_pKp, pcnt, sm);
+    const double alpha = ctrl->val[V_RZ] / pKp;
+    double a = 0.0, c = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * Kp[i];
+        r[i] = ri;
+        const double zi = ri / dg[i];
+        z[i] = zi;
+        a += ri * zi; c += ri * ri;
+    }
+    double ta = block_sum(a, sm), tc = block_sum(c, sm + 4);
+    if (threadIdx.x == 0) { p_rz[blockIdx.x] = ta; p_rr[blockIdx.x] = tc; }
+}
+// scalar step: convergence latch, beta, rz roll-over (single block)
+__global__ __launch_bounds__(256) void k_pcg_scalar(Ctrl *ctrl, const double *__restrict__ p_rz, const double *__restrict__ p_rr, int cnt,
+                                                    double tol) {
+    __shared__ double sm[8];
+    if (ctrl->cnt[C_PCG_DONE]) return;
+    const double rz2 = reduce_partials(p_rz, cnt, sm), rr = reduce_partials(p_rr, cnt, sm + 4);
+    if (threadIdx.x == 0) {
+        ctrl->cnt[C_PCG_IT] += 1;
+        if (sqrt(rr) <= tol * ctrl->val[V_BNORM] || !(rr == rr)) ctrl->cnt[C_PCG_DONE] = 1;
+        ctrl->val[V_RR] = rz2 / ctrl->val[V_RZ];     // beta
+        ctrl->val[V_RZ] = rz2;
+    }
+}
+__global__ void k_pcg_p(int n, const Ctrl *__restrict__ ctrl, const double *__restrict__ z, double *__restrict__ p) {
+    if (ctrl->cnt[C_PCG_DONE]) return;
+    const double beta = ctrl->val[V_RR];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = z[i] + beta * p[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact linesearch (linesearch.c:74-158): stable LSD radix sort of the 2m breakpoints on the
+// 64-bit pattern of t (positive doubles order as unsigned integers; non-candidates carry a
+// sentinel key and sort last; ties keep index order like glibc's merge-sort qsort), then an
+// exclusive scan of the slope/intercept increments and a first-crossing search.
+// ------------------------------------------------------------------------------------------------
+static const int RS_ITEMS = 8;                       // keys per thread per tile
+static const int RS_TILE = BLK * RS_ITEMS;           // 2048
+
+__global__ __launch_bounds__(256) void k_rs_hist(const u64 *__restrict__ keys, int N, int shift, int nblocks, int *__restrict__ hist) {
+    __shared__ int lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE;
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const int i = base + r * BLK + threadIdx.x;
+        if (i < N) atomicAdd(&lh[(int)((keys[i] >> shift) & 255ull)], 1);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nblocks + blockIdx.x] = lh[threadIdx.x];
+}
+// exclusive scan of hist (digit-major, length 256*nblocks) by one block
+__global__ __launch_bounds__(256) void k_rs_scan(int *__restrict__ hist, int total) {
+    __shared__ int sums[256];
+    const int chunk = (total + 255) / 256;
+    const int beg = threadIdx.x * chunk, end = min(beg + chunk, total);
+    int s = 0;
+    for (int i = beg; i < end; i++) s += hist[i];
+    sums[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; i++) { int t = sums[i]; sums[i] = run; run += t; } }
+    __syncthreads();
+    int run = sums[threadIdx.x];
+    for (int i = beg; i < end; i++) { int t = hist[i]; hist[i] = run; run += t; }
+}
+__global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ kin, const u32 *__restrict__ vin, u64 *__restrict__ kout,
+                                                    u32 *__restrict__ vout, int N, int shift, int nblocks,
+                                                    const int *__restrict__ hist) {
+    __shared__ int base[256];
+    __shared__ int cnt[4][256];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    base[tid] = hist[tid * nblocks + blockIdx.x];
+    const int tile = blockIdx.x * RS_TILE;
+    for (int r = 0; r < RS_ITEMS; r++) {
+        for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
+        __syncthreads();
+        const int i = tile + r * BLK + tid;
+        const bool valid = i < N;
+        u64 key = 0; u32 val = 0; int dig = 0;
+        if (valid) { key = kin[i]; val = vin[i]; dig = (int)((key >> shift) & 255ull); }
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const u64 bal = __ballot(valid && ((dig >> b) & 1));
+            peers &= ((dig >> b) & 1) ? bal : ~bal;
+        }
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) cnt[wave][dig] = __popcll(peers);
+        __syncthreads();
+        if (valid) {
+            int off = base[dig] + rank;
+            for (int w = 0; w < wave; w++) off += cnt[w][dig];
+            kout[off] = key; vout[off] = val;
+        }
+        __syncthreads();
+        base[tid] += cnt[0][tid] + cnt[1][tid] + cnt[2][tid] + cnt[3][tid];
+        __syncthreads();
+    }
+}
+
+static const int LS_ITEMS = 4;
+static const int LS_TILE = BLK * LS_ITEMS;           // 1024 breakpoints per block
+// per-block exclusive scan of (da, db) over the sorted breakpoints; block totals to bt
+__global__ __launch_bounds__(256) void k_ls_scan1(const Ctrl *__restrict__ ctrl, const u32 *__restrict__ idx,
+                                                  const double *__restrict__ delta, const double *__restrict__ alpha,
+                                                  double *__restrict__ pa, double *__restrict__ pb, double *__restrict__ bt, int nblk) {
+    __shared__ double sa[256], sb[256];
+    const int nL = ctrl->cnt[C_NL];
+    const int base = blockIdx.x * LS_TILE + threadIdx.x * LS_ITEMS;
+    double da[LS_ITEMS], db[LS_ITEMS], ta = 0.0, tb = 0.0;
+#pragma unroll
+    for (int j = 0; j < LS_ITEMS; j++) {
+        const int k = base + j;
+        da[j] = 0.0; db[j] = 0.0;
+        if (k < nL) {
+            const u32 iz = idx[k];
+            const double dl = delta[iz], al = alpha[iz];
+            if (dl > 0) { da[j] = dl * dl; db[j] = -(dl * al); }      // linesearch.c:135-137
+            else        { da[j] = -(dl * dl); db[j] = dl * al; }      // linesearch.c:138-140
+        }
+        ta += da[j]; tb += db[j];
+    }
+    sa[threadIdx.x] = ta; sb[threadIdx.x] = tb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ra = 0.0, rb = 0.0;
+        for (int i = 0; i < 256; i++) { double t1 = sa[i], t2 = sb[i]; sa[i] = ra; sb[i] = rb; ra += t1; rb += t2; }
+        bt[blockIdx.x] = ra; bt[nblk + blockIdx.x] = rb;
+    }
+    __syncthreads();
+    double ra = sa[threadIdx.x], rb = sb[threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < LS_ITEMS; j++) {
+        const int k = base + j;
+        if (k < nL) { pa[k] = ra; pb[k] = rb; }
+        ra += da[j]; rb += db[j];
+    }
+}
+// one block: a0, b0 from the partial sums (linesearch.c:19-25,119-120), exclusive scan of block totals
+__global__ __launch_bounds__(256) void k_ls_scan2(Ctrl *ctrl, const double *__restrict__ part, int pm, int pn, double *__restrict__ bt, int nblk) {
+    __shared__ double sm[8];
+    const double eta_m = reduce_partials(part + P_ETA_M * PGRID, pm, sm);
+    const double beta_m = reduce_partials(part + P_BETA_M * PGRID, pm, sm + 4);
+    const double ja = reduce_partials(part + P_A0 * PGRID, pm, sm);
+    const double jb = reduce_partials(part + P_B0 * PGRID, pm, sm + 4);
+    const double dxQdx = reduce_partials(part + P_DXQDX * PGRID, pn, sm);
+    const double dxdf = reduce_partials(part + P_DXDF * PGRID, pn, sm + 4);
+    if (threadIdx.x == 0) {
+        double eta = eta_m; eta += dxQdx; eta *= 0.5;
+        double beta = beta_m; beta += dxdf; beta *= 0.5;
+        ctrl->val[V_A0] = eta + ja;
+        ctrl->val[V_B0] = beta - jb;
+        ctrl->cnt[C_KSTAR] = 0x7fffffff;
+        const int nL = ctrl->cnt[C_NL];
+        const int used = (nL + LS_TILE - 1) / LS_TILE;
+        double ra = 0.0, rb = 0.0;
+        for (int i = 0; i < used; i++) {
+            double t1 = bt[i], t2 = bt[nblk + i];
+            bt[i] = ra; bt[nblk + i] = rb; ra += t1; rb += t2;
+        }
+        bt[2 * nblk] = ra; bt[2 * nblk + 1] = rb;     // grand totals
+    }
+}
+__global__ __launch_bounds__(256) void k_ls_search(Ctrl *ctrl, const u64 *__restrict__ key, const double *__restrict__ pa,
+                                                   const double *__restrict__ pb, const double *__restrict__ bt, int nblk) {
+    const int nL = ctrl->cnt[C_NL];
+    const double a0 = ctrl->val[V_A0], b0 = ctrl->val[V_B0];
+    int best = 0x7fffffff;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nL; k += gridDim.x * blockDim.x) {
+        const int blk = k / LS_TILE;
+        const double a = a0 + (bt[blk] + pa[k]), b = b0 + (bt[nblk + blk] + pb[k]);
+        const double t = __longlong_as_double((long long)key[k]);
+        if (b + a * t > 0) { best = k; break; }       // ascending k per thread: first hit is its minimum
+    }
+    if (best != 0x7fffffff) atomicMin(&ctrl->cnt[C_KSTAR], best);
+}
+__global__ void k_ls_final(Ctrl *ctrl, const double *__restrict__ pa, const double *__restrict__ pb, const double *__restrict__ bt, int nblk) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int nL = ctrl->cnt[C_NL];
+    const double a0 = ctrl->val[V_A0], b0 = ctrl->val[V_B0];
+    const int ks = ctrl->cnt[C_KSTAR];
+    double a, b;
+    if (nL == 0) { a = a0; b = b0; }
+    else if (ks >= nL) { a = a0 + bt[2 * nblk]; b = b0 + bt[2 * nblk + 1]; }
+    else { const int blk = ks / LS_TILE; a = a0 + (bt[blk] + pa[ks]); b = b0 + (bt[nblk + blk] + pb[ks]); }
+    ctrl->val[V_TAU] = -b / a;
+}
+// standalone prep for the linesearch parity entry point (caller supplies eta, beta, delta, alpha)
+__global__ __launch_bounds__(256) void k_ls_prep_raw(int M2, const double *__restrict__ delta, const double *__restrict__ alpha,
+                                                     u64 *__restrict__ key, u32 *__restrict__ idx, double *__restrict__ p_a0,
+                                                     double *__restrict__ p_b0, Ctrl *ctrl) {
+    __shared__ double sm[8];
+    double a0 = 0.0, b0 = 0.0; int nL = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M2; i += gridDim.x * blockDim.x) {
+        const double dl = delta[i], al = alpha[i], t = al / dl;
+        const bool L = t > 0, P = dl > 0;
+        key[i] = L ? (u64)__double_as_longlong(t) : KEY_SENTINEL;
+        idx[i] = (u32)i;
+        if (L) nL++;
+        if (L != P) { a0 += dl * dl; b0 += dl * al; }
+    }
+    double t3 = block_sum(a0, sm), t4 = block_sum(b0, sm + 4);
+    int tn = block_sum_int(nL, (int *)sm);
+    if (threadIdx.x == 0) { p_a0[blockIdx.x] = t3; p_b0[blockIdx.x] = t4; if (tn) atomicAdd(&ctrl->cnt[C_NL], tn); }
+}
+__global__ void k_set_partial(double *p, double v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
+__global__ void k_ctrl_set_int(Ctrl *c, int slot, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) c->cnt[slot] = v; }
+
+// ================================================================================================
+// host side of the backend
+// ================================================================================================
+template <class T>
+static int dev_alloc(QpdoDev *d, T **p, size_t count) {
+    void *q = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIPCHK(hipMalloc(&q, bytes));
+    HIPCHK(hipMemsetAsync(q, 0, bytes, d->stream));
+    d->allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+static int pick_tpr(const DevCsr &M) {
+    const double avg = M.nrows ? (double)M.nnz / (double)M.nrows : 0.0;
+    if (avg > 48) return 64;
+    if (avg > 24) return 32;
+    if (avg > 12) return 16;
+    if (avg > 6) return 8;
+    return 4;
+}
+static int upload_csr(QpdoDev *d, DevCsr *M, const QdevCsr *h) {
+    M->nrows = h->nrows; M->ncols = h->ncols; M->nnz = h->nnz;
+    int rc;
+    if ((rc = dev_alloc(d, &M->rp, (size_t)h->nrows + 1))) return rc;
+    if ((rc = dev_alloc(d, &M->ci, (size_t)h->nnz))) return rc;
+    if ((rc = dev_alloc(d, &M->val, (size_t)h->nnz))) return rc;
+    HIPCHK(hipMemcpyAsync(M->rp, h->rp, ((size_t)h->nrows + 1) * sizeof(int), hipMemcpyHostToDevice, d->stream));
+    if (h->nnz) {
+        HIPCHK(hipMemcpyAsync(M->ci, h->ci, (size_t)h->nnz * sizeof(int), hipMemcpyHostToDevice, d->stream));
+        HIPCHK(hipMemcpyAsync(M->val, h->val, (size_t)h->nnz * sizeof(double), hipMemcpyHostToDevice, d->stream));
+    }
+    M->tpr = pick_tpr(*M);
+    return 0;
+}
+static int read_ctrl(QpdoDev *d) {
+    HIPCHK(hipMemcpyAsync(d->hctrl, d->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+static inline double nrm_of(const Ctrl *c, int slot) {
+    double v; u64 b = c->nrm[slot]; memcpy(&v, &b, 8); return v;
+}
+#define LAUNCH(kernel, grid, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLK), 0, d->stream, __VA_ARGS__)
+
+extern "C" {
+
+int qdev_device_count(void) { int c = 0; if (hipGetDeviceCount(&c) != hipSuccess) return 0; return c; }
+const char *qdev_last_error(void) { return g_err; }
+
+int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *Ar, const QdevCsr *At, const QdevCsr *Qf,
+                const double *q, const double *l, const double *u) {
+    *out = nullptr;
+    HIPCHK(hipSetDevice(device));
+    QpdoDev *d = new QpdoDev();
+    d->device = device; d->n = n; d->m = m;
+    int rc = 0;
+    hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete d; return set_err(e, "hipStreamCreate", __LINE__); }
+#define A_(p, cnt) if (!rc) rc = dev_alloc(d, &d->p, (size_t)(cnt))
+    if (!rc) rc = upload_csr(d, &d->Ar, Ar);
+    if (!rc) rc = upload_csr(d, &d->At, At);
+    if (!rc) rc = upload_csr(d, &d->Qf, Qf);
+    A_(x, n); A_(xbar, n); A_(Qx, n); A_(Aty, n); A_(q, n); A_(df, n); A_(res_dual, n); A_(res_dual_in, n); A_(rhs, n);
+    A_(dx, n); A_(Qdx, n); A_(Atdy, n); A_(D, n); A_(Dinv, n);
+    A_(pc_r, n); A_(pc_z, n); A_(pc_p, n); A_(pc_Kp, n); A_(pc_diag, n); A_(tmp_n, n);
+    A_(y, m); A_(ybar, m); A_(Ax, m); A_(l, m); A_(u, m); A_(mu, m); A_(isq, m); A_(w, m); A_(res_prim, m);
+    A_(res_prim_old, m); A_(res_prim_in, m); A_(dy, m); A_(Adx, m); A_(d, m); A_(E, m); A_(Einv, m); A_(pc_t, m);
+    A_(at_scale, m); A_(tmp_m, m);
+    A_(active, m); A_(active_old, m); A_(mu_changed, m);
+    const size_t M2 = 2 * (size_t)m;
+    A_(ls_delta, M2); A_(ls_alpha, M2); A_(ls_pa, M2); A_(ls_pb, M2);
+    A_(ls_key[0], M2); A_(ls_key[1], M2); A_(ls_idx[0], M2); A_(ls_idx[1], M2);
+    d->rs_nblocks = (int)((M2 + RS_TILE - 1) / RS_TILE); if (d->rs_nblocks < 1) d->rs_nblocks = 1;
+    A_(rs_hist, (size_t)256 * d->rs_nblocks);
+    d->ls_nblk = (int)((M2 + LS_TILE - 1) / LS_TILE); if (d->ls_nblk < 1) d->ls_nblk = 1;
+    A_(ls_bt, (size_t)2 * d->ls_nblk + 2);
+    A_(ctrl, 1); A_(part, (size_t)P_COUNT * PGRID);
+#undef A_
+    if (!rc) { e = hipHostMalloc((void **)&d->hctrl, sizeof(Ctrl), hipHostMallocDefault); if (e != hipSuccess) rc = set_err(e, "hipHostMalloc", __LINE__); }
+    if (!rc) { e = hipEventCreate(&d->ev0); if (e == hipSuccess) e = hipEventCreate(&d->ev1); if (e != hipSuccess) rc = set_err(e, "hipEventCreate", __LINE__); }
+    if (!rc) {
+        e = hipMemcpyAsync(d->q, q, (size_t)n * 8, hipMemcpyHostToDevice, d->stream);
+        if (e == hipSuccess && m) e = hipMemcpyAsync(d->l, l, (size_t)m * 8, hipMemcpyHostToDevice, d->stream);
+        if (e == hipSuccess && m) e = hipMemcpyAsync(d->u, u, (size_t)m * 8, hipMemcpyHostToDevice, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        if (e != hipSuccess) rc = set_err(e, "upload", __LINE__);
+    }
+    if (rc) { qdev_destroy(d); return rc; }
+    d->st.linsolve = 0;
+    *out = d;
+    return 0;
+}
+
+void qdev_destroy(QpdoDev *d) {
+    if (!d) return;
+    hipSetDevice(d->device);
+    if (d->stream) hipStreamSynchronize(d->stream);
+    for (void *p : d->allocs) hipFree(p);
+    if (d->hctrl) hipHostFree(d->hctrl);
+    if (d->ev0) hipEventDestroy(d->ev0);
+    if (d->ev1) hipEventDestroy(d->ev1);
+    if (d->stream) hipStreamDestroy(d->stream);
+    delete d;
+}
+int qdev_sync(QpdoDev *d) { HIPCHK(hipSetDevice(d->device)); HIPCHK(hipStreamSynchronize(d->stream)); return 0; }
+
+int qdev_configure(QpdoDev *d, int linsolve, double pcg_tol, int pcg_maxit) {
+    if (linsolve >= 0) d->linsolve = linsolve;
+    if (pcg_tol > 0) d->pcg_tol = pcg_tol;
+    if (pcg_maxit > 0) d->pcg_maxit = pcg_maxit;
+    d->st.linsolve = d->linsolve;
+    return 0;
+}
+int qdev_get_stats(QpdoDev *d, QdevStats *out) { *out = d->st; return 0; }
+int qdev_get_spmv_sample(QpdoDev *d, double *avg_seconds, long *samples) {
+    *samples = (long)d->ev_spmv_n;
+    *avg_seconds = d->ev_spmv_n ? d->ev_spmv_ms * 1e-3 / (double)d->ev_spmv_n : 0.0;
+    return 0;
+}
+int qdev_reset_stats(QpdoDev *d) { int ls = d->st.linsolve; d->st = QdevStats{}; d->st.linsolve = ls; d->ev_spmv_ms = 0; d->ev_spmv_n = 0; return 0; }
+
+// ---- scaling (scaling.c:24-91) ------------------------------------------------------------------
+int qdev_scale_data(QpdoDev *d, int iters, int use_Qx, double *D_host, double *E_host, double *c_out) {
+    HIPCHK(hipSetDevice(d->device));
+    const int n = d->n, m = d->m;
+    LAUNCH(k_fill, vgrid(n), n, 1.0, d->D);
+    LAUNCH(k_fill, vgrid(m), m, 1.0, d->E);
+    const int gAt = spmv_grid(d->At, d->At.tpr, false), gAr = spmv_grid(d->Ar, d->Ar.tpr, false);
+    for (int it = 0; it < iters; it++) {
+        // column norms of A = row norms of CSR(A'); row norms of A = row norms of CSR(A)
+        DISPATCH_TPR(d->At, k_row_absmax, gAt, n, d->At.rp, d->At.val, d->tmp_n);
+        DISPATCH_TPR(d->Ar, k_row_absmax, gAr, m, d->Ar.rp, d->Ar.val, d->tmp_m);
+        LAUNCH(k_ruiz_factor, vgrid(n), n, d->tmp_n, d->D);
+        LAUNCH(k_ruiz_factor, vgrid(m), m, d->tmp_m, d->E);
+        // A <- E A D: (a * E_i) * D_j on both stored copies
+        DISPATCH_TPR(d->Ar, k_scale_rows_cols, gAr, m, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)d->tmp_m, (const double *)nullptr,
+                     (const double *)nullptr, (const double *)d->tmp_n);
+        DISPATCH_TPR(d->At, k_scale_rows_cols, gAt, n, d->At.rp, d->At.ci, d->At.val, (const double *)nullptr, (const double *)d->tmp_m,
+                     (const double *)d->tmp_n, (const double *)nullptr);
+    }
+    const int gQ = spmv_grid(d->Qf, d->Qf.tpr, false);
+    DISPATCH_TPR(d->Qf, k_scale_sym, gQ, n, d->Qf.rp, d->Qf.ci, d->Qf.val, (const double *)d->D);
+    LAUNCH(k_mul, vgrid(n), n, d->D, d->q, d->q);                    // q <- D q
+    // cost scaling: c = 1 / max(1, ||Qx + q||inf)
+    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
+    LAUNCH(k_absmax_axpy, vgrid(n), n, (const double *)d->q, use_Qx ? (const double *)d->Qx : (const double *)nullptr, 1.0, d->ctrl, N_A);
+    int rc = read_ctrl(d); if (rc) return rc;
+    const double nq = nrm_of(d->hctrl, N_A);
+    const double c = 1 / (1.0 > nq ? 1.0 : nq);
+    // q <- c q (vec_self_mult_scalar), Q <- c Q
+    LAUNCH(k_scal, vgrid(n), n, c, d->q);
+    if (d->Qf.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qf.nnz, d->Qf.val, c);
+    HIPCHK(hipMemcpyAsync(D_host, d->D, (size_t)n * 8, hipMemcpyDeviceToHost, d->stream));
+    if (m) HIPCHK(hipMemcpyAsync(E_host, d->E, (size_t)m * 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    *c_out = c;
+    return 0;
+}
+int qdev_set_scaling(QpdoDev *d, int scaled, const double *D, const double *Dinv, const double *E, const double *Einv, double c, double cinv) {
+    HIPCHK(hipSetDevice(d->device));
+    d->scaled = scaled; d->sc_c = c; d->sc_cinv = cinv;
+    if (scaled) {
+        HIPCHK(hipMemcpyAsync(d->D, D, (size_t)d->n * 8, hipMemcpyHostToDevice, d->stream));
+        HIPCHK(hipMemcpyAsync(d->Dinv, Dinv, (size_t)d->n * 8, hipMemcpyHostToDevice, d->stream));
+        if (d->m) {
+            HIPCHK(hipMemcpyAsync(d->E, E, (size_t)d->m * 8, hipMemcpyHostToDevice, d->stream));
+            HIPCHK(hipMemcpyAsync(d->Einv, Einv, (size_t)d->m * 8, hipMemcpyHostToDevice, d->stream));
+        }
+        HIPCHK(hipStreamSynchronize(d->stream));
+    }
+    return 0;
+}
+int qdev_upload_bounds(QpdoDev *d, const double *l, const double *u) {
+    HIPCHK(hipSetDevice(d->device));
+    if (d->m) {
+        if (l) HIPCHK(hipMemcpyAsync(d->l, l, (size_t)d->m * 8, hipMemcpyHostToDevice, d->stream));
+        if (u) HIPCHK(hipMemcpyAsync(d->u, u, (size_t)d->m * 8, hipMemcpyHostToDevice, d->stream));
+    }
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+int qdev_upload_q(QpdoDev *d, const double *q) {
+    HIPCHK(hipSetDevice(d->device));
+    HIPCHK(hipMemcpyAsync(d->q, q, (size_t)d->n * 8, hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+int qdev_download_q(QpdoDev *d, double *q) {
+    HIPCHK(hipSetDevice(d->device));
+    HIPCHK(hipMemcpyAsync(q, d->q, (size_t)d->n * 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+int qdev_scale_Q_values(QpdoDev *d, double factor) {
+    HIPCHK(hipSetDevice(d->device));
+    if (d->Qf.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qf.nnz, d->Qf.val, factor);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static double *vec_by_id(QpdoDev *d, int which, size_t *len) {
+    switch (which) {
+        case 0: *len = d->n; return d->x;
+        case 1: *len = d->n; return d->Qx;
+        case 2: *len = d->m; return d->y;
+        case 3: *len = d->m; return d->mu;
+        case 4: *len = d->m; return d->d;
+        case 5: *len = d->n; return d->dx;
+        case 6: *len = d->m; return d->dy;
+        case 7: *len = d->m; return d->Ax;
+        case 8: *len = d->n; return d->Aty;
+        case 9: *len = d->m; return d->l;
+        case 10: *len = d->m; return d->u;
+    }
+    *len = 0; return nullptr;
+}
+int qdev_download_vec(QpdoDev *d, int which, double *dst) {
+    HIPCHK(hipSetDevice(d->device));
+    size_t len; double *p = vec_by_id(d, which, &len);
+    if (!p) return -1;
+    if (len) HIPCHK(hipMemcpyAsync(dst, p, len * 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+int qdev_upload_vec(QpdoDev *d, int which, const double *src) {
+    HIPCHK(hipSetDevice(d->device));
+    size_t len; double *p = vec_by_id(d, which, &len);
+    if (!p) return -1;
+    if (len) HIPCHK(hipMemcpyAsync(p, src, len * 8, hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+// ---- warm start (qpdo.c:217-299, iteration.c:98-122) ---------------------------------------------
+int qdev_objective(QpdoDev *d, int proximal, double sigma, double c_const, double *objective) {
+    HIPCHK(hipSetDevice(d->device));
+    const int g = vgrid(d->n);
+    LAUNCH(k_objective, g, d->n, proximal, sigma, d->x, d->Qx, d->q, d->part + P_OBJ * PGRID);
+    LAUNCH(k_reduce_to_ctrl, 1, d->part + P_OBJ * PGRID, g, d->ctrl, V_OBJ);
+    int rc = read_ctrl(d); if (rc) return rc;
+    double obj = d->hctrl->val[V_OBJ];
+    if (d->scaled) obj *= d->sc_cinv;
+    obj += c_const;
+    *objective = obj;
+    return 0;
+}
+int qdev_warm_start(QpdoDev *d, const double *x_ws, const double *y_ws, int proximal, double sigma, double mu_min,
+                    double c_const, double *objective) {
+    HIPCHK(hipSetDevice(d->device));
+    const int n = d->n, m = d->m;
+    (void)mu_min;
+    *objective = 0.0;
+    if (x_ws) {
+        HIPCHK(hipMemcpyAsync(d->tmp_n, x_ws, (size_t)n * 8, hipMemcpyHostToDevice, d->stream));
+        LAUNCH(k_ws_x, vgrid(n), n, d->scaled, d->tmp_n, d->Dinv, d->x, d->xbar);
+        launch_spmv(d, d->Qf, d->x, EpiQpure{d->x, sigma, proximal, d->Qx}, false);
+        launch_spmv(d, d->Ar, d->x, EpiStore{d->Ax}, false);
+        int rc = qdev_objective(d, proximal, sigma, c_const, objective); if (rc) return rc;
+    } else {
+        HIPCHK(hipMemsetAsync(d->x, 0, (size_t)n * 8, d->stream));
+        HIPCHK(hipMemsetAsync(d->xbar, 0, (size_t)n * 8, d->stream));
+        HIPCHK(hipMemsetAsync(d->Qx, 0, (size_t)n * 8, d->stream));
+        if (m) HIPCHK(hipMemsetAsync(d->Ax, 0, (size_t)m * 8, d->stream));
+    }
+    if (y_ws && m) {
+        HIPCHK(hipMemcpyAsync(d->tmp_m, y_ws, (size_t)m * 8, hipMemcpyHostToDevice, d->stream));
+        LAUNCH(k_ws_y, vgrid(m), m, d->scaled, d->sc_c, d->tmp_m, d->Einv, d->y, d->ybar);
+        launch_spmv(d, d->At, d->y, EpiStore{d->Aty}, false);
+    } else {
+        if (m) { HIPCHK(hipMemsetAsync(d->y, 0, (size_t)m * 8, d->stream)); HIPCHK(hipMemsetAsync(d->ybar, 0, (size_t)m * 8, d->stream)); }
+        HIPCHK(hipMemsetAsync(d->Aty, 0, (size_t)n * 8, d->stream));
+    }
+    const int g = vgrid(n);
+    LAUNCH(k_dots_f, g, n, d->x, d->Qx, d->q, d->part + P_F1 * PGRID, d->part + P_F2 * PGRID);
+    LAUNCH(k_init_mu, vgrid(m), m, d->part + P_F1 * PGRID, d->part + P_F2 * PGRID, g, d->Ax, d->l, d->u, d->mu, d->isq);
+    HIPCHK(hipStreamSynchronize(d->stream));   // x_ws / y_ws host buffers may be released by the caller
+    return 0;
+}
+int qdev_begin_solve(QpdoDev *d) {
+    HIPCHK(hipSetDevice(d->device));
+    if (d->m) HIPCHK(hipMemsetAsync(d->active_old, 0, (size_t)d->m * sizeof(int), d->stream));
+    return 0;
+}
+
+// ---- residual pass ---------------------------------------------------------------------------------
+int qdev_residuals(QpdoDev *d, int proximal, double sigma, QdevResid *out) {
+    HIPCHK(hipSetDevice(d->device));
+    const int n = d->n, m = d->m;
+    LAUNCH(k_ctrl_clear_pass, 1, d->ctrl);
+    LAUNCH(k_resid_m, vgrid(m), m, d->scaled, d->sc_cinv, d->Ax, d->y, d->ybar, d->mu, d->l, d->u, d->E, d->Einv, d->res_prim, d->w,
+           d->res_prim_in, d->active, d->active_old, d->ctrl);
+    LAUNCH(k_resid_n, vgrid(n), n, d->scaled, proximal, sigma, d->Qx, d->q, d->x, d->xbar, d->Aty, d->Dinv, d->df, d->res_dual,
+           d->res_dual_in, d->ctrl);
+    int rc = read_ctrl(d); if (rc) return rc;
+    const Ctrl *c = d->hctrl;
+    out->res_prim = nrm_of(c, N_PRIM);
+    out->res_prim_in = nrm_of(c, N_PRIM_IN);
+    out->res_dual = nrm_of(c, N_DUAL);
+    out->res_dual_in = nrm_of(c, N_DUAL_IN);
+    if (d->scaled) { out->res_dual *= d->sc_cinv; out->res_dual_in *= d->sc_cinv; }   // termination.c:45,72
+    out->n_active = c->cnt[C_ACTIVE]; out->n_enter = c->cnt[C_ENTER]; out->n_leave = c->cnt[C_LEAVE];
+    return 0;
+}
+
+// ---- linear solve -----------------------------------------------------------------------------------
+static int pcg_solve(QpdoDev *d, int *iters_out) {
+    const int n = d->n;
+    const int gq = spmv_grid(d->Qf, d->Qf.tpr, false);
+    // Jacobi diagonal
+    LAUNCH(k_extract_diag, vgrid(n), n, d->Qf.rp, d->Qf.ci, d->Qf.val, d->tmp_n);
+    (void)gq;
+    const int gAt = spmv_grid(d->At, d->At.tpr, false);
+    DISPATCH_TPR(d->At, k_jacobi_diag, gAt, n, d->At.rp, d->At.ci, d->At.val, (const double *)d->d, (const double *)d->tmp_n, d->sigma_f, d->pc_diag);
+    const int g = vgrid(n);
+    double *P = d->part;
+    LAUNCH(k_pcg_init, g, n, d->rhs, d->pc_diag, d->dx, d->pc_r, d->pc_z, d->pc_p, P + P_RZ * PGRID, P + P_RR * PGRID);
+    LAUNCH(k_pcg_init2, 1, P + P_RZ * PGRID, P + P_RR * PGRID, g, d->ctrl);
+    const int pAt = spmv_pgrid(d->At);
+    int it = 0;
+    while (it < d->pcg_maxit) {
+        const int it_before = it;
+        int batch = d->pcg_batch; if (it + batch > d->pcg_maxit) batch = d->pcg_maxit - it;
+        for (int b = 0; b < batch; b++) {
+            launch_spmv_pcg(d, d->Ar, d->pc_p, EpiPcgA{d->d, d->pc_t, nullptr}, false);
+            launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQ{d->pc_p, d->sigma_f, d->pc_Kp}, false);
+            const bool sample = (b == 0);
+            if (sample) hipEventRecord(d->ev0, d->stream);
+            launch_spmv_pcg(d, d->At, d->pc_t, EpiPcgAt{d->pc_p, d->pc_Kp, P + P_PKP * PGRID}, true);
+            if (sample) hipEventRecord(d->ev1, d->stream);
+            LAUNCH(k_pcg_update, g, n, d->ctrl, P + P_PKP * PGRID, pAt, d->pc_p, d->pc_Kp, d->pc_diag, d->dx, d->pc_r, d->pc_z,
+                   P + P_RZ * PGRID, P + P_RR * PGRID);
+            LAUNCH(k_pcg_scalar, 1, d->ctrl, P + P_RZ * PGRID, P + P_RR * PGRID, g, d->pcg_tol);
+            LAUNCH(k_pcg_p, g, n, d->ctrl, d->pc_z, d->pc_p);
+        }
+        it += batch;
+        int rc = read_ctrl(d); if (rc) return rc;
+        if (d->hctrl->cnt[C_PCG_IT] > it_before) {      // the sampled (first) iteration of this batch really ran
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, d->ev0, d->ev1) == hipSuccess) { d->ev_spmv_ms += ms; d->ev_spmv_n++; }
+        }
+        if (d->hctrl->cnt[C_PCG_DONE]) break;
+    }
+    *iters_out = d->hctrl->cnt[C_PCG_IT];
+    return 0;
+}
+
+// ---- linesearch sort + scan + search (shared by the Newton step and the parity entry point) -----------
+static int linesearch_device(QpdoDev *d, int pm, int pn) {
+    const int M2 = 2 * d->m;
+    int cur = 0;
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = 8 * pass;
+        LAUNCH(k_rs_hist, d->rs_nblocks, d->ls_key[cur], M2, shift, d->rs_nblocks, d->rs_hist);
+        LAUNCH(k_rs_scan, 1, d->rs_hist, 256 * d->rs_nblocks);
+        LAUNCH(k_rs_scatter, d->rs_nblocks, d->ls_key[cur], d->ls_idx[cur], d->ls_key[1 - cur], d->ls_idx[1 - cur], M2, shift,
+               d->rs_nblocks, d->rs_hist);
+        cur = 1 - cur;
+    }
+    // 8 passes: result back in buffer 0
+    LAUNCH(k_ls_scan1, d->ls_nblk, d->ctrl, d->ls_idx[cur], d->ls_delta, d->ls_alpha, d->ls_pa, d->ls_pb, d->ls_bt, d->ls_nblk);
+    LAUNCH(k_ls_scan2, 1, d->ctrl, d->part, pm, pn, d->ls_bt, d->ls_nblk);
+    LAUNCH(k_ls_search, vgrid(M2), d->ctrl, d->ls_key[cur], d->ls_pa, d->ls_pb, d->ls_bt, d->ls_nblk);
+    LAUNCH(k_ls_final, 1, d->ctrl, d->ls_pa, d->ls_pb, d->ls_bt, d->ls_nblk);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- one Newton step (iteration.c:11-25) ----------------------------------------------------------------
+int qdev_newton_step(QpdoDev *d, int branch, int proximal, double sigma, double *tau_out, int *lin_iters_out) {
+    HIPCHK(hipSetDevice(d->device));
+    const int n = d->n, m = d->m;
+    if (branch == 0 || branch == 2) d->sigma_f = proximal ? sigma : 0.0;     // ldlchol beta (cholmod_interface.c:11-13)
+    LAUNCH(k_newton_prep, vgrid(m), m, branch, d->active, d->active_old, d->isq, d->mu, d->res_prim_in, d->d, d->dy);
+    launch_spmv(d, d->At, d->dy, EpiRhs{d->res_dual_in, d->Atdy, d->rhs}, false);
+    int lin = 0;
+    int rc = pcg_solve(d, &lin); if (rc) return rc;
+    d->st.lin_iters += lin;
+    *lin_iters_out = lin;
+    // Qdx (+ sigma dx), n-side dots
+    launch_spmv(d, d->Qf, d->dx, EpiQdx{d->dx, d->df, sigma, proximal, d->Qdx, d->part + P_DXQDX * PGRID, d->part + P_DXDF * PGRID}, true);
+    LAUNCH(k_ctrl_set_int, 1, d->ctrl, C_NL, 0);
+    EpiAdxLs e{};
+    e.m = m; e.mu = d->mu; e.isq = d->isq; e.w = d->w; e.l = d->l; e.u = d->u; e.y = d->y; e.active = d->active; e.active_old = d->active_old;
+    e.Adx = d->Adx; e.dy = d->dy; e.delta = d->ls_delta; e.alpha = d->ls_alpha; e.key = d->ls_key[0]; e.idx = d->ls_idx[0];
+    e.p_eta = d->part + P_ETA_M * PGRID; e.p_beta = d->part + P_BETA_M * PGRID; e.p_a0 = d->part + P_A0 * PGRID; e.p_b0 = d->part + P_B0 * PGRID;
+    e.ctrl = d->ctrl;
+    launch_spmv(d, d->Ar, d->dx, e, true);
+    launch_spmv(d, d->At, d->dy, EpiStore{d->Atdy}, false);
+    rc = linesearch_device(d, spmv_pgrid(d->Ar), spmv_pgrid(d->Qf)); if (rc) return rc;
+    LAUNCH(k_axpy5, vgrid(n > m ? n : m), n, m, d->ctrl, d->x, d->dx, d->Qx, d->Qdx, d->Aty, d->Atdy, d->y, d->dy, d->Ax, d->Adx);
+    rc = read_ctrl(d); if (rc) return rc;
+    *tau_out = d->hctrl->val[V_TAU];
+    d->st.newton_passes++;
+    return 0;
+}
+
+// ---- outer-update helpers ---------------------------------------------------------------------------------
+int qdev_primal_infeasibility(QpdoDev *d, double eps_prim_inf, int *is_infeasible) {
+    HIPCHK(hipSetDevice(d->device));
+    const int n = d->n, m = d->m;
+    *is_infeasible = 0;
+    LAUNCH(k_sub, vgrid(m), m, d->y, d->ybar, d->dy);                                  // qpdo.c:372
+    launch_spmv(d, d->At, d->dy, EpiStore{d->Atdy}, false);                            // qpdo.c:374
+    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
+    LAUNCH(k_absmax_mul, vgrid(m), m, (const double *)d->dy, d->scaled ? (const double *)d->E : (const double *)nullptr, d->ctrl, N_A);
+    int rc = read_ctrl(d); if (rc) return rc;
+    const double eps = eps_prim_inf * nrm_of(d->hctrl, N_A);
+    if (eps == 0) return 0;
+    LAUNCH(k_pinf_n, vgrid(n), n, d->scaled, d->Dinv, d->Atdy, d->ctrl);
+    const int g = vgrid(m);
+    LAUNCH(k_pinf_m, g, m, d->scaled, d->dy, d->l, d->u, d->E, d->part + P_OOB * PGRID);
+    LAUNCH(k_reduce_to_ctrl, 1, d->part + P_OOB * PGRID, g, d->ctrl, V_OOB);
+    rc = read_ctrl(d); if (rc) return rc;
+    const double nAtdy = nrm_of(d->hctrl, N_B), oob = d->hctrl->val[V_OOB];
+    if ((nAtdy <= eps) && (oob <= -eps)) {
+        *is_infeasible = 1;
+        if (d->scaled) LAUNCH(k_pinf_cert, vgrid(m), m, d->sc_cinv, d->E, d->dy);
+    }
+    return 0;
+}
+int qdev_dual_infeasibility(QpdoDev *d, int proximal, double sigma, double tau, double eps_dual_inf, int *is_infeasible) {
+    HIPCHK(hipSetDevice(d->device));
+    const int n = d->n, m = d->m;
+    *is_infeasible = 0;
+    LAUNCH(k_sub, vgrid(n), n, d->x, d->xbar, d->dx);                                  // qpdo.c:383
+    launch_spmv(d, d->Qf, d->dx, EpiStore{d->Qdx}, false);                             // qpdo.c:385 (no sigma)
+    launch_spmv(d, d->Ar, d->dx, EpiStore{d->Adx}, false);                             // qpdo.c:387
+    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
+    LAUNCH(k_absmax_mul, vgrid(n), n, (const double *)d->dx, d->scaled ? (const double *)d->D : (const double *)nullptr, d->ctrl, N_C);
+    int rc = read_ctrl(d); if (rc) return rc;
+    const double eps = eps_dual_inf * nrm_of(d->hctrl, N_C);
+    if (eps == 0) return 0;
+    LAUNCH(k_dinf_m, vgrid(m), m, d->scaled, eps, d->Einv, d->E, d->l, d->u, d->Adx, d->ctrl);
+    rc = read_ctrl(d); if (rc) return rc;
+    if (d->hctrl->cnt[C_VIOL]) return 0;
+    const int g = vgrid(n);
+    LAUNCH(k_dinf_n, g, n, proximal, -sigma * tau, d->dx, d->q, d->Qdx, d->ctrl, d->part + P_QDX * PGRID);
+    LAUNCH(k_reduce_to_ctrl, 1, d->part + P_QDX * PGRID, g, d->ctrl, V_QDX);
+    rc = read_ctrl(d); if (rc) return rc;
+    const double nQdx = nrm_of(d->hctrl, N_D), qdx = d->hctrl->val[V_QDX];
+    const double c = d->scaled ? d->sc_c : 1.0;
+    const bool ok = d->scaled ? ((nQdx <= c * eps) && (qdx <= -c * eps)) : ((nQdx <= eps) && (qdx <= -eps));
+    if (ok) {
+        *is_infeasible = 1;
+        if (d->scaled) LAUNCH(k_mul, vgrid(n), n, d->D, d->dx, d->dx);
+    }
+    return 0;
+}
+int qdev_shift_estimates(QpdoDev *d) {
+    HIPCHK(hipSetDevice(d->device));
+    HIPCHK(hipMemcpyAsync(d->xbar, d->x, (size_t)d->n * 8, hipMemcpyDeviceToDevice, d->stream));
+    if (d->m) HIPCHK(hipMemcpyAsync(d->ybar, d->y, (size_t)d->m * 8, hipMemcpyDeviceToDevice, d->stream));
+    return 0;
+}
+int qdev_update_mu(QpdoDev *d, double eps_abs, double theta, double delta, double mu_min, double isq_mu_min, int *n_changed) {
+    HIPCHK(hipSetDevice(d->device));
+    const int m = d->m;
+    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
+    LAUNCH(k_absmax_mul, vgrid(m), m, (const double *)d->res_prim, (const double *)nullptr, d->ctrl, N_A);     // iteration.c:130
+    LAUNCH(k_update_mu, vgrid(m), m, eps_abs, theta, delta, mu_min, isq_mu_min, (const Ctrl *)d->ctrl, d->res_prim, d->res_prim_old,
+           d->mu, d->isq, d->at_scale, d->mu_changed, d->ctrl);
+    int rc = read_ctrl(d); if (rc) return rc;
+    *n_changed = d->hctrl->cnt[C_MUCH];
+    return 0;
+}
+int qdev_mu_changed_update(QpdoDev *d) {
+    HIPCHK(hipSetDevice(d->device));
+    LAUNCH(k_mu_changed_d, vgrid(d->m), d->m, d->mu_changed, d->at_scale, d->isq, d->d);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int qdev_update_sigma(QpdoDev *d, double sigma_new, double sigma_old) {
+    HIPCHK(hipSetDevice(d->device));
+    LAUNCH(k_axpy, vgrid(d->n), d->n, sigma_new - sigma_old, d->x, d->Qx);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int qdev_save_res_prim(QpdoDev *d) {
+    HIPCHK(hipSetDevice(d->device));
+    if (d->m) HIPCHK(hipMemcpyAsync(d->res_prim_old, d->res_prim, (size_t)d->m * 8, hipMemcpyDeviceToDevice, d->stream));
+    return 0;
+}
+int qdev_store_solution(QpdoDev *d, double *sol_x, double *sol_y, double *x, double *y, double *dx, double *dy) {
+    HIPCHK(hipSetDevice(d->device));
+    const int n = d->n, m = d->m;
+    LAUNCH(k_store_solution, vgrid(n > m ? n : m), n, m, d->scaled, d->sc_cinv, d->x, d->D, d->y, d->E, d->tmp_n, d->tmp_m);
+    HIPCHK(hipMemcpyAsync(sol_x, d->tmp_n, (size_t)n * 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipMemcpyAsync(x, d->x, (size_t)n * 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipMemcpyAsync(dx, d->dx, (size_t)n * 8, hipMemcpyDeviceToHost, d->stream));
+    if (m) {
+        HIPCHK(hipMemcpyAsync(sol_y, d->tmp_m, (size_t)m * 8, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipMemcpyAsync(y, d->y, (size_t)m * 8, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipMemcpyAsync(dy, d->dy, (size_t)m * 8, hipMemcpyDeviceToHost, d->stream));
+    }
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+// ---- measurement + parity entry points ---------------------------------------------------------------------
+static DevCsr *mat_by_id(QpdoDev *d, int which) { return which == 0 ? &d->Ar : which == 1 ? &d->At : &d->Qf; }
+
+int qdev_bench_spmv(QpdoDev *d, int which, int reps, double *avg_seconds, double *alg_bytes) {
+    HIPCHK(hipSetDevice(d->device));
+    DevCsr *M = mat_by_id(d, which);
+    double *xin = (M->ncols == d->n) ? d->pc_p : d->pc_t;
+    double *yout = (M->nrows == d->n) ? d->pc_Kp : d->tmp_m;
+    LAUNCH(k_fill, vgrid(M->ncols), M->ncols, 1.0, xin);
+    launch_spmv(d, *M, xin, EpiStore{yout}, false);     // warm-up
+    HIPCHK(hipEventRecord(d->ev0, d->stream));
+    for (int r = 0; r < reps; r++) launch_spmv(d, *M, xin, EpiStore{yout}, false);
+    HIPCHK(hipEventRecord(d->ev1, d->stream));
+    HIPCHK(hipEventSynchronize(d->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, d->ev0, d->ev1));
+    *avg_seconds = (double)ms * 1e-3 / (double)reps;
+    *alg_bytes = M->alg_bytes();
+    return 0;
+}
+int qdev_spmv(QpdoDev *d, int which, const double *v_host, double *y_host) {
+    HIPCHK(hipSetDevice(d->device));
+    DevCsr *M = mat_by_id(d, which);
+    double *xin = (M->ncols == d->n) ? d->pc_p : d->pc_t;
+    double *yout = (M->nrows == d->n) ? d->pc_Kp : d->tmp_m;
+    if (M->ncols) HIPCHK(hipMemcpyAsync(xin, v_host, (size_t)M->ncols * 8, hipMemcpyHostToDevice, d->stream));
+    launch_spmv(d, *M, xin, EpiStore{yout}, false);
+    if (M->nrows) HIPCHK(hipMemcpyAsync(y_host, yout, (size_t)M->nrows * 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+int qdev_linesearch(QpdoDev *d, double eta, double beta, const double *delta, const double *alpha, double *tau) {
+    HIPCHK(hipSetDevice(d->device));
+    const int M2 = 2 * d->m;
+    if (M2 == 0) { *tau = -beta / eta; return 0; }
+    HIPCHK(hipMemcpyAsync(d->ls_delta, delta, (size_t)M2 * 8, hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemcpyAsync(d->ls_alpha, alpha, (size_t)M2 * 8, hipMemcpyHostToDevice, d->stream));
+    LAUNCH(k_ctrl_set_int, 1, d->ctrl, C_NL, 0);
+    const int g = vgrid(M2);
+    LAUNCH(k_ls_prep_raw, g, M2, d->ls_delta, d->ls_alpha, d->ls_key[0], d->ls_idx[0], d->part + P_A0 * PGRID, d->part + P_B0 * PGRID, d->ctrl);
+    // eta, beta enter through the partial slots so that k_ls_scan2 forms a0, b0 exactly as in a Newton step:
+    // eta = 0.5*(eta_m + dxQdx) with eta_m = 2*eta, dxQdx = 0
+    hipLaunchKernelGGL(k_set_partial, dim3(1), dim3(1), 0, d->stream, d->part + P_ETA_M * PGRID, 2.0 * eta);
+    hipLaunchKernelGGL(k_set_partial, dim3(1), dim3(1), 0, d->stream, d->part + P_BETA_M * PGRID, 2.0 * beta);
+    hipLaunchKernelGGL(k_set_partial, dim3(1), dim3(1), 0, d->stream, d->part + P_DXQDX * PGRID, 0.0);
+    hipLaunchKernelGGL(k_set_partial, dim3(1), dim3(1), 0, d->stream, d->part + P_DXDF * PGRID, 0.0);
+    // pm applies to ETA/BETA (1 value) and A0/B0 (g values): run scan2 with pm = g after zero-padding ETA/BETA slots
+    if (g > 1) {
+        HIPCHK(hipMemsetAsync(d->part + P_ETA_M * PGRID + 1, 0, (size_t)(g - 1) * 8, d->stream));
+        HIPCHK(hipMemsetAsync(d->part + P_BETA_M * PGRID + 1, 0, (size_t)(g - 1) * 8, d->stream));
+    }
+    int rc = linesearch_device(d, g, 1); if (rc) return rc;
+    rc = read_ctrl(d); if (rc) return rc;
+    *tau = d->hctrl->val[V_TAU];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, exports every
+symbol include/*.h declares, and refuses to run without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from qpdo_amd import _build, problems, solver
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(qpdo_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(_build.ensure_lib())
+    api = declared_symbols("qpdo.h")
+    ext = declared_symbols("qpdo_amd_ext.h")
+    assert sorted(api) == sorted(solver.API_SYMBOLS)
+    assert sorted(ext) == sorted(solver.EXT_SYMBOLS)
+    for s in api + ext:
+        assert hasattr(L, s), s
+
+
+def test_default_settings_match_reference_constants():
+    """reference include/constants.h:44-69"""
+    s = solver.default_settings()
+    exp = dict(max_time=1e20, max_iter=10000, inner_max_iter=1000, eps_abs=1e-6, eps_abs_in=1.0, eps_prim_inf=1e-6,
+               eps_dual_inf=1e-6, rho=0.1, theta=0.25, delta=1e-2, mu_min=1e-9, proximal=1, sigma_init=1e-3,
+               sigma_upd=1e-1, sigma_min=1e-7, scaling=10, verbose=1, print_interval=1, reset_newton_iter=1000)
+    for k, v in exp.items():
+        assert getattr(s, k) == v, k
+    with pytest.raises(KeyError):
+        solver.default_settings(not_a_setting=1)
+
+
+def test_struct_layout_sizes():
+    """x86-64 LP64 sizes of the public structs in the DLONG+PROFILING layout"""
+    assert C.sizeof(solver.QPDOSettings) == 19 * 8
+    assert C.sizeof(solver.QPDOInfo) == 2 * 8 + 32 + 8 + 8 * 8
+    assert C.sizeof(solver.QPDOData) == 8 * 8
+    assert C.sizeof(solver.CholmodSparse) == 8 * 8 + 6 * 4
+
+
+def test_setup_returns_null_on_invalid_input(capfd):
+    p = problems.config_qp("C1b")
+    with pytest.raises(RuntimeError):          # l > u: validate_data (reference src/validate.c:20-28)
+        solver.QPDO().setup(p["Q"], p["q"], p["A"], p["u"] + 1.0, p["u"], Qstype=-1, verbose=0)
+    with pytest.raises(RuntimeError):          # validate_settings
+        solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0, rho=2.0)
+    out = capfd.readouterr().out
+    assert "Data validation returned failure" in out and "Settings validation returned failure" in out
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful where no GPU exists")
+def test_no_cpu_fallback_without_device(capfd):
+    p = problems.config_qp("C1b")
+    with pytest.raises(RuntimeError):
+        solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0)
+    assert "no HIP device" in capfd.readouterr().out
+
+
+def test_generator_is_deterministic_and_psd():
+    a, b = problems.random_qp(3, 60, 90, 0.1), problems.random_qp(3, 60, 90, 0.1)
+    assert (a["A"] != b["A"]).nnz == 0 and (a["Q"] != b["Q"]).nnz == 0 and np.array_equal(a["q"], b["q"])
+    Q = problems.full_Q(a).toarray()
+    assert np.allclose(Q, Q.T) and np.linalg.eigvalsh(Q).min() > 0
+    assert (a["l"] <= a["u"]).all()
+    c3 = problems.config_qp("C3")
+    assert (c3["l"][:120] == c3["u"][:120]).all() and (c3["l"][120:] < c3["u"][120:]).all()

@@ -1,0 +1,125 @@
+"""Unit specifications the reference leaves as commented-out debug blocks:
+ (i)  after newton_direction: ||(Q+sigma I)dx + A'dy + res_dual_in||inf ~ 0 and
+      ||(I-P)A dx - (I-P/2) mu.*dy + res_prim_in||inf ~ 0   (reference src/newton.c:71-90)
+ (ii) after the linesearch: eta t + beta + delta'[delta t - alpha]_+ ~ 0 at t = tau
+      (reference src/linesearch.c:53-66)
+plus independent checks of the restated pieces against numpy/scipy."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import binding as ob
+from qpdo_amd import problems
+
+
+def psi_prime(t, eta, beta, delta, alpha):
+    return eta * t + beta + delta @ np.maximum(delta * t - alpha, 0.0)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("m", [1, 7, 200, 3000])
+def test_pwa_linesearch_is_root(seed, m):
+    rng = np.random.default_rng(seed)
+    delta = rng.standard_normal(2 * m)
+    delta[m:] = -delta[:m]
+    alpha = np.abs(rng.standard_normal(2 * m)) * rng.choice([1.0, -0.3], 2 * m)
+    if m >= 7:                                   # equality rows: exact ties t_i == t_{i+m}
+        alpha[m:m + 3] = -alpha[:3]
+        delta[5] = 0.0; delta[m + 5] = 0.0       # 0-slope row: t = +-inf or nan
+    eta = 0.7 + rng.random()
+    # descent direction: psi'(0+) = beta + sum over terms active at 0+ of (-delta*alpha) must be negative
+    with np.errstate(divide="ignore", invalid="ignore"):
+        act0 = ((alpha / delta) > 0) != (delta > 0)
+    beta = -abs(float(-(delta[act0] * alpha[act0]).sum())) - 0.5 - rng.random()
+    tau = ob.pwa_linesearch(eta, beta, delta, alpha)
+    assert tau > 0
+    scale = abs(beta) + eta * abs(tau) + np.abs(delta) @ np.abs(delta * tau - alpha)
+    assert abs(psi_prime(tau, eta, beta, delta, alpha)) <= 1e-12 * scale
+
+
+def test_csc_mv_against_scipy():
+    p = problems.random_qp(5, 300, 500, 0.05)
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(300), rng.standard_normal(500)
+    np.testing.assert_allclose(ob.csc_mv(p["A"], x), p["A"] @ x, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ob.csc_mv(p["A"], y, trans=True), p["A"].T @ y, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ob.csc_mv(p["Q"], x, stype=-1), problems.full_Q(p) @ x, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ob.csc_mv(sp.triu(problems.full_Q(p)).tocsc(), x, stype=1), problems.full_Q(p) @ x,
+                               rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("scaling", [0, 10])
+def test_newton_direction_residuals(scaling):
+    """spec (i) on the direction of the last Newton pass of a short run"""
+    p = problems.config_qp("C1")
+    s = ob.default_settings(max_iter=5, scaling=scaling)
+    o = ob.OracleSolver(p, s)
+    o.solve()
+    # scaled data as the oracle holds it
+    A = sp.csc_matrix((o.vec("Ax_vals") if False else np.ctypeslib.as_array(ob.lib().oracle_vec(o.h, 12), shape=(p["A"].nnz,)).copy(),
+                       p["A"].indices, p["A"].indptr), shape=p["A"].shape)
+    mu, dx, dy = o.vec("mu"), o.vec("dx"), o.vec("dy")
+    Qdx, Adx, Atdy = o.vec("Qdx"), o.vec("Adx"), o.vec("Atdy")
+    rpi, rdi = o.vec("res_prim_in"), o.vec("res_dual_in")
+    np.testing.assert_allclose(A @ dx, Adx, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(A.T @ dy, Atdy, rtol=1e-11, atol=1e-12)
+    a1 = np.abs(Qdx + Atdy + rdi).max()          # Qdx already holds (Q + sigma I) dx
+    d = o.vec("d")
+    act = d != 0
+    r2 = rpi.copy()
+    r2[act] += Adx[act] - dy[act] * mu[act]
+    r2[~act] -= 0.5 * dy[~act] * mu[~act]
+    scale = max(1.0, np.abs(rdi).max(), np.abs(rpi).max())
+    assert a1 <= 1e-9 * scale and np.abs(r2).max() <= 1e-9 * scale
+    o.close()
+
+
+def test_solution_satisfies_kkt_independently():
+    for name in ["C1", "C1b", "C3"]:
+        p = problems.config_qp(name)
+        o = ob.OracleSolver(p, ob.default_settings())
+        r = o.solve()
+        assert r["info"]["status_val"] == 1
+        rp, rd = problems.kkt_residuals(p, r["x"], r["y"])
+        assert rp <= 1e-6 and rd <= 1e-6
+        assert abs(rp - r["info"]["res_prim_norm"]) <= 1e-9 and abs(rd - r["info"]["res_dual_norm"]) <= 1e-9
+        o.close()
+
+
+def test_dense_and_pcg_modes_agree():
+    p = problems.config_qp("C3", 2)
+    a = ob.OracleSolver(p, ob.default_settings()).solve()
+    b = ob.OracleSolver(p, ob.default_settings(), linsolve="pcg", pcg_tol=1e-12).solve()
+    assert (a["info"]["status_val"], a["info"]["iterations"], a["info"]["oterations"]) == \
+           (b["info"]["status_val"], b["info"]["iterations"], b["info"]["oterations"])
+    np.testing.assert_allclose(a["x"], b["x"], rtol=0, atol=1e-9)
+
+
+def test_validation_contract():
+    """NULL-return contract of qpdo_setup (reference src/validate.c)"""
+    p = problems.config_qp("C1b")
+    bad = dict(p); bad["l"] = p["u"] + 1.0
+    assert not ob.OracleSolver(bad, ob.default_settings()).ok
+    for k, v in [("max_iter", 0), ("rho", 1.0), ("theta", 0.0), ("delta", 1.0), ("mu_min", 0.0), ("proximal", 2),
+                 ("sigma_init", 0.0), ("sigma_upd", 1.5), ("sigma_min", 1.0), ("scaling", -1), ("eps_abs", 0.0)]:
+        assert not ob.OracleSolver(p, ob.default_settings(**{k: v})).ok, k
+
+
+def test_warm_start_and_updates_sequence():
+    p = problems.config_qp("C1")
+    o = ob.OracleSolver(p, ob.default_settings())
+    r1 = o.solve()
+    rng = np.random.default_rng(0)
+    o.warm_start(r1["x"] + 1e-3 * rng.standard_normal(p["n"]), r1["y"] + 1e-3 * rng.standard_normal(p["m"]))
+    r2 = o.solve()
+    assert r2["info"]["status_val"] == 1 and r2["info"]["iterations"] < r1["info"]["iterations"]
+    o.update_bounds(p["l"] - 0.1, p["u"] + 0.1)
+    r3 = o.solve()
+    p3 = dict(p); p3["l"], p3["u"] = p["l"] - 0.1, p["u"] + 0.1
+    assert r3["info"]["status_val"] == 1 and max(problems.kkt_residuals(p3, r3["x"], r3["y"])) <= 1e-6
+    qn = p["q"] * 1.5
+    o.update_q(qn)
+    r4 = o.solve()
+    p4 = dict(p3); p4["q"] = qn
+    assert r4["info"]["status_val"] == 1 and max(problems.kkt_residuals(p4, r4["x"], r4["y"])) <= 1e-6
+    o.close()
