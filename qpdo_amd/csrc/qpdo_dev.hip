@@ -61,6 +61,10 @@ struct DevCsr {
     int *rp = nullptr, *ci = nullptr;
     double *val = nullptr;
     int tpr = 64;            // threads cooperating on one row
+    // LDS-staged variant: columns are cut into `nslabs` slabs of W columns; sp[r*(nslabs+1)+s] is the
+    // position inside row r where slab s starts (rows are column-sorted, so a slab is a sub-range)
+    int use_slab = 0, nslabs = 0, W = 0, rows_per_wg = 0, slab_grid = 0;
+    int *sp = nullptr;
     double alg_bytes() const { return 12.0 * (double)nnz + 4.0 * (nrows + 1) + 8.0 * nrows + 8.0 * ncols; }
 };
 
@@ -185,7 +189,7 @@ __device__ __forceinline__ double group_sum(double v) {
 template <int TPR, class Epi>
 __global__ __launch_bounds__(256) void k_spmv(int nrows, const int *__restrict__ rp, const int *__restrict__ ci,
                                               const double *__restrict__ val, const double *__restrict__ x, Epi epi) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     const int lane = threadIdx.x % TPR;
     const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
     const int ngroups = gridDim.x * (BLK / TPR);
@@ -209,6 +213,88 @@ __global__ __launch_bounds__(256) void k_spmv(int nrows, const int *__restrict__
     epi.finish(sm);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged SpMV for matrices that stream from HBM (BASELINE north star: "coalesced CSR row loads
+// staged in LDS with wavefront __shfl reductions").  One 1024-thread workgroup per CU owns a block of
+// consecutive rows and walks the column slabs; for each slab the x-slice (W doubles, up to ~150 KB)
+// is copied once into LDS with coalesced loads, then 16-lane groups stream their rows' sub-ranges
+// (contiguous val / col-index runs) and gather x from LDS instead of from L2.  Row sums accumulate
+// in LDS across slabs in a fixed order, so results are reproducible.
+// ------------------------------------------------------------------------------------------------
+static const int SLAB_THREADS = 1024;
+static const int SLAB_TPR = 16;
+template <class Epi>
+__global__ __launch_bounds__(1024) void k_spmv_slab(const int *__restrict__ done, int nrows, int ncols, int nslabs, int W,
+                                                    int rows_per_wg, const int *__restrict__ sp, const int *__restrict__ ci,
+                                                    const double *__restrict__ val, const double *__restrict__ x, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double sm[32];
+    if (done && *done) return;
+    double *xs = lds;
+    double *acc = lds + W;
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * rows_per_wg;
+    const int R = min(rows_per_wg, nrows - row0);
+    for (int r = tid; r < R; r += SLAB_THREADS) acc[r] = 0.0;
+    const int lane = tid & (SLAB_TPR - 1);
+    const int grp = tid / SLAB_TPR;
+    const int ngrp = SLAB_THREADS / SLAB_TPR;
+    for (int s = 0; s < nslabs; s++) {
+        const int c0 = s * W;
+        const int cw = min(W, ncols - c0);
+        __syncthreads();
+        {   // stage x[c0 .. c0+cw) : 16-byte loads, then the odd tail
+            const int pairs = cw >> 1;
+            const double2 *src = reinterpret_cast<const double2 *>(x + c0);
+            double2 *dst = reinterpret_cast<double2 *>(xs);
+            for (int i = tid; i < pairs; i += SLAB_THREADS) dst[i] = src[i];
+            if ((cw & 1) && tid == 0) xs[cw - 1] = x[c0 + cw - 1];
+        }
+        __syncthreads();
+        for (int r = grp; r < R; r += ngrp) {
+            const int row = row0 + r;
+            if (epi.skip(row)) continue;
+            const int *spr = sp + (size_t)row * (nslabs + 1) + s;
+            const int beg = spr[0], end = spr[1];
+            double s0 = 0.0, s1 = 0.0;
+            int k = beg + lane;
+            for (; k + SLAB_TPR < end; k += 2 * SLAB_TPR) {
+                const double v0 = val[k], v1 = val[k + SLAB_TPR];
+                const int a0 = ci[k] - c0, a1 = ci[k + SLAB_TPR] - c0;
+                s0 += v0 * xs[a0];
+                s1 += v1 * xs[a1];
+            }
+            if (k < end) s0 += val[k] * xs[ci[k] - c0];
+            double t = s0 + s1;
+#pragma unroll
+            for (int o = SLAB_TPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, SLAB_TPR);
+            if (lane == 0) acc[r] += t;
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < R; r += SLAB_THREADS) epi.row(row0 + r, acc[r]);
+    epi.finish(sm);
+}
+// slab pointers by binary search in each (column-sorted) row; also flags unsorted rows
+__global__ void k_build_slab_ptr(int nrows, const int *__restrict__ rp, const int *__restrict__ ci, int nslabs, int W,
+                                 int *__restrict__ sp, int *__restrict__ unsorted) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+        const int b = rp[r], e = rp[r + 1];
+        int bad = 0;
+        for (int k = b + 1; k < e; k++) bad |= (ci[k] < ci[k - 1]);
+        if (bad) atomicOr(unsorted, 1);
+        int *o = sp + (size_t)r * (nslabs + 1);
+        for (int s = 0; s < nslabs; s++) {
+            const int target = s * W;
+            int lo = b, hi = e;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ci[mid] < target) lo = mid + 1; else hi = mid; }
+            o[s] = lo;
+        }
+        o[nslabs] = e;
+    }
+}
+
 struct EpiStore {                          // y = M x
     double *y;
     __device__ bool skip(int) const { return false; }
@@ -230,7 +316,7 @@ struct EpiQdx {                            // newton.c:52-55 + the two n-dots of
         Qdx[r] = v; a1 += dx[r] * v; a2 += dx[r] * df[r];
     }
     __device__ void finish(double *sm) {
-        double t1 = block_sum(a1, sm), t2 = block_sum(a2, sm + 4);
+        double t1 = block_sum(a1, sm), t2 = block_sum(a2, sm + 16);
         if (threadIdx.x == 0) { p_dxQdx[blockIdx.x] = t1; p_dxdf[blockIdx.x] = t2; }
     }
 };
@@ -274,8 +360,8 @@ struct EpiAdxLs {
         cand(r + m, c0, ahi);
     }
     __device__ void finish(double *sm) {
-        double t1 = block_sum(e, sm), t2 = block_sum(b, sm + 4);
-        double t3 = block_sum(a0, sm), t4 = block_sum(b0, sm + 4);
+        double t1 = block_sum(e, sm), t2 = block_sum(b, sm + 16);
+        double t3 = block_sum(a0, sm), t4 = block_sum(b0, sm + 16);
         int tn = block_sum_int(nL, (int *)sm);
         if (threadIdx.x == 0) {
             p_eta[blockIdx.x] = t1; p_beta[blockIdx.x] = t2; p_a0[blockIdx.x] = t3; p_b0[blockIdx.x] = t4;
@@ -306,6 +392,7 @@ struct EpiPcgAt {                          // Kp += A' t ; partial p.Kp
 };
 
 static inline int spmv_grid(const DevCsr &M, int tpr, bool partials) {
+    if (M.use_slab) return M.slab_grid;
     long long groups_per_block = BLK / tpr;
     long long g = (M.nrows + groups_per_block - 1) / groups_per_block;
     long long cap = partials ? PGRID : 4096;
@@ -314,8 +401,22 @@ static inline int spmv_grid(const DevCsr &M, int tpr, bool partials) {
     return (int)g;
 }
 template <class Epi>
+static void launch_spmv_slab(QpdoDev *d, const DevCsr &M, const double *x, Epi epi, const int *done) {
+    const size_t lds = ((size_t)M.W + (size_t)M.rows_per_wg) * sizeof(double);
+    static thread_local bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_spmv_slab<Epi>), dim3(M.slab_grid), dim3(SLAB_THREADS), lds, d->stream, done, M.nrows, M.ncols, M.nslabs, M.W,
+                       M.rows_per_wg, M.sp, M.ci, M.val, x, epi);
+    d->st.spmv_calls++;
+    d->st.spmv_bytes += (int64_t)M.alg_bytes();
+}
+template <class Epi>
 static void launch_spmv(QpdoDev *d, const DevCsr &M, const double *x, Epi epi, bool partials) {
     const int g = spmv_grid(M, M.tpr, partials);
+    if (M.use_slab) { launch_spmv_slab(d, M, x, epi, (const int *)nullptr); return; }
     switch (M.tpr) {
         case 4:  hipLaunchKernelGGL((k_spmv<4, Epi>),  dim3(g), dim3(BLK), 0, d->stream, M.nrows, M.rp, M.ci, M.val, x, epi); break;
         case 8:  hipLaunchKernelGGL((k_spmv<8, Epi>),  dim3(g), dim3(BLK), 0, d->stream, M.nrows, M.rp, M.ci, M.val, x, epi); break;
@@ -334,7 +435,7 @@ template <int TPR, class Epi>
 __global__ __launch_bounds__(256) void k_spmv_pcg(const int *__restrict__ done, int nrows, const int *__restrict__ rp,
                                                   const int *__restrict__ ci, const double *__restrict__ val,
                                                   const double *__restrict__ x, Epi epi) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     if (*done) return;
     const int lane = threadIdx.x % TPR;
     const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
@@ -362,6 +463,7 @@ template <class Epi>
 static void launch_spmv_pcg(QpdoDev *d, const DevCsr &M, const double *x, Epi epi, bool partials) {
     const int g = spmv_grid(M, M.tpr, partials);
     const int *done = &d->ctrl->cnt[C_PCG_DONE];
+    if (M.use_slab) { launch_spmv_slab(d, M, x, epi, done); return; }
     switch (M.tpr) {
         case 4:  hipLaunchKernelGGL((k_spmv_pcg<4, Epi>),  dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
         case 8:  hipLaunchKernelGGL((k_spmv_pcg<8, Epi>),  dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
@@ -482,7 +584,7 @@ __global__ __launch_bounds__(256) void k_resid_m(int m, int scaled, double cinv,
                                                  const double *__restrict__ Einv, double *__restrict__ res_prim,
                                                  double *__restrict__ w, double *__restrict__ res_prim_in,
                                                  int *__restrict__ active, const int *__restrict__ active_old, Ctrl *ctrl) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     double mx1 = 0.0, mx2 = 0.0; int na = 0, ne = 0, nl = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         const double ax = Ax[i], yi = y[i], li = l[i], ui = u[i], mui = mu[i], yb = ybar[i];
@@ -505,7 +607,7 @@ __global__ __launch_bounds__(256) void k_resid_m(int m, int scaled, double cinv,
         mx2 = absmax_acc(mx2, scaled ? Einv[i] * rpi : rpi);
     }
     block_max_to(mx1, &ctrl->nrm[N_PRIM], sm);
-    block_max_to(mx2, &ctrl->nrm[N_PRIM_IN], sm + 4);
+    block_max_to(mx2, &ctrl->nrm[N_PRIM_IN], sm + 16);
     int ta = block_sum_int(na, (int *)sm), te = block_sum_int(ne, (int *)sm), tl = block_sum_int(nl, (int *)sm);
     if (threadIdx.x == 0) {
         if (ta) atomicAdd(&ctrl->cnt[C_ACTIVE], ta);
@@ -519,7 +621,7 @@ __global__ __launch_bounds__(256) void k_resid_n(int n, int scaled, int prox, do
                                                  const double *__restrict__ xbar, const double *__restrict__ Aty,
                                                  const double *__restrict__ Dinv, double *__restrict__ df,
                                                  double *__restrict__ res_dual, double *__restrict__ res_dual_in, Ctrl *ctrl) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     double mx1 = 0.0, mx2 = 0.0;
     const double ns = -sigma;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
@@ -533,7 +635,7 @@ __global__ __launch_bounds__(256) void k_resid_n(int n, int scaled, int prox, do
         mx2 = absmax_acc(mx2, scaled ? Dinv[j] * rdi : rdi);
     }
     block_max_to(mx1, &ctrl->nrm[N_DUAL], sm);
-    block_max_to(mx2, &ctrl->nrm[N_DUAL_IN], sm + 4);
+    block_max_to(mx2, &ctrl->nrm[N_DUAL_IN], sm + 16);
 }
 
 // factor-state weights d (cholmod_interface.c:35-72 as rules on d) + t = (I+P) res_prim_in ./ mu (newton.c:37-40)
@@ -599,7 +701,7 @@ __global__ void k_recip(int n, const double *__restrict__ a, double *__restrict_
 // max |a + sc*b| into ctrl->nrm[slot]
 __global__ __launch_bounds__(256) void k_absmax_axpy(int n, const double *__restrict__ a, const double *__restrict__ b, double sc,
                                                      Ctrl *ctrl, int slot) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     double mx = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         mx = absmax_acc(mx, b ? a[i] + sc * b[i] : a[i]);
@@ -607,7 +709,7 @@ __global__ __launch_bounds__(256) void k_absmax_axpy(int n, const double *__rest
 }
 __global__ __launch_bounds__(256) void k_absmax_mul(int n, const double *__restrict__ a, const double *__restrict__ b,
                                                     Ctrl *ctrl, int slot) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     double mx = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         mx = absmax_acc(mx, b ? a[i] * b[i] : a[i]);
@@ -634,16 +736,16 @@ __global__ void k_ws_y(int m, int scaled, double c, const double *__restrict__ y
 // partial dots for f = 0.5 x'Qx + q'x (iteration.c:102) and the objective (iteration.c:185-221)
 __global__ __launch_bounds__(256) void k_dots_f(int n, const double *__restrict__ x, const double *__restrict__ Qx,
                                                 const double *__restrict__ q, double *__restrict__ p1, double *__restrict__ p2) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     double a = 0.0, b = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { a += x[i] * Qx[i]; b += q[i] * x[i]; }
-    double ta = block_sum(a, sm), tb = block_sum(b, sm + 4);
+    double ta = block_sum(a, sm), tb = block_sum(b, sm + 16);
     if (threadIdx.x == 0) { p1[blockIdx.x] = ta; p2[blockIdx.x] = tb; }
 }
 __global__ __launch_bounds__(256) void k_objective(int n, int prox, double sigma, const double *__restrict__ x,
                                                    const double *__restrict__ Qx, const double *__restrict__ q,
                                                    double *__restrict__ p) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     double a = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         a += prox ? (0.5 * (Qx[i] - x[i] * sigma) + q[i]) * x[i] : (0.5 * Qx[i] + q[i]) * x[i];
@@ -651,7 +753,7 @@ __global__ __launch_bounds__(256) void k_objective(int n, int prox, double sigma
     if (threadIdx.x == 0) p[blockIdx.x] = t;
 }
 __global__ __launch_bounds__(256) void k_reduce_to_ctrl(const double *__restrict__ p, int cnt, Ctrl *ctrl, int slot) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     double t = reduce_partials(p, cnt, sm);
     if (threadIdx.x == 0) ctrl->val[slot] = t;
 }
@@ -659,8 +761,8 @@ __global__ __launch_bounds__(256) void k_reduce_to_ctrl(const double *__restrict
 __global__ __launch_bounds__(256) void k_init_mu(int m, const double *__restrict__ p1, const double *__restrict__ p2, int pcnt,
                                                  const double *__restrict__ Ax, const double *__restrict__ l,
                                                  const double *__restrict__ u, double *__restrict__ mu, double *__restrict__ isq) {
-    __shared__ double sm[8];
-    const double xQx = reduce_partials(p1, pcnt, sm), qx = reduce_partials(p2, pcnt, sm + 4);
+    __shared__ double sm[32];
+    const double xQx = reduce_partials(p1, pcnt, sm), qx = reduce_partials(p2, pcnt, sm + 16);
     const double f = 0.5 * xQx + qx;
     const double af = f < 0 ? -f : f;
     const double den = 1 > af ? 1 : af;
@@ -682,7 +784,7 @@ __global__ __launch_bounds__(256) void k_init_mu(int m, const double *__restrict
 // primal, stage 2: Atdy <- Dinv .* Atdy (n-part) ; oob partials (m-part)
 __global__ __launch_bounds__(256) void k_pinf_n(int n, int scaled, const double *__restrict__ Dinv, double *__restrict__ Atdy,
                                                 Ctrl *ctrl) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     double mx = 0.0;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
         double v = Atdy[j];
@@ -694,7 +796,7 @@ __global__ __launch_bounds__(256) void k_pinf_n(int n, int scaled, const double 
 __global__ __launch_bounds__(256) void k_pinf_m(int m, int scaled, const double *__restrict__ dy, const double *__restrict__ l,
                                                 const double *__restrict__ u, const double *__restrict__ E,
                                                 double *__restrict__ part) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     double s = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         const double e = scaled ? E[i] : 1.0, v = dy[i];
@@ -726,7 +828,7 @@ __global__ void k_dinf_m(int m, int scaled, double eps, const double *__restrict
 // dual, stage 3: Qdx += (-sigma*tau) dx ; ||Qdx||inf ; partial q.dx
 __global__ __launch_bounds__(256) void k_dinf_n(int n, int prox, double st, const double *__restrict__ dx, const double *__restrict__ q,
                                                 double *__restrict__ Qdx, Ctrl *ctrl, double *__restrict__ part) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     double mx = 0.0, s = 0.0;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
         double v = Qdx[j];
@@ -735,7 +837,7 @@ __global__ __launch_bounds__(256) void k_dinf_n(int n, int prox, double st, cons
         s += q[j] * dx[j];
     }
     block_max_to(mx, &ctrl->nrm[N_D], sm);
-    double t = block_sum(s, sm + 4);
+    double t = block_sum(s, sm + 16);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
@@ -808,19 +910,19 @@ __global__ void k_store_solution(int n, int m, int scaled, double cinv, const do
 __global__ __launch_bounds__(256) void k_pcg_init(int n, const double *__restrict__ b, const double *__restrict__ dg,
                                                   double *__restrict__ x, double *__restrict__ r, double *__restrict__ z,
                                                   double *__restrict__ p, double *__restrict__ p_rz, double *__restrict__ p_bb) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     double a = 0.0, c = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double bi = b[i], zi = bi / dg[i];
         x[i] = 0.0; r[i] = bi; z[i] = zi; p[i] = zi;
         a += bi * zi; c += bi * bi;
     }
-    double ta = block_sum(a, sm), tc = block_sum(c, sm + 4);
+    double ta = block_sum(a, sm), tc = block_sum(c, sm + 16);
     if (threadIdx.x == 0) { p_rz[blockIdx.x] = ta; p_bb[blockIdx.x] = tc; }
 }
 __global__ __launch_bounds__(256) void k_pcg_init2(const double *__restrict__ p_rz, const double *__restrict__ p_bb, int cnt, Ctrl *ctrl) {
-    __shared__ double sm[8];
-    double rz = reduce_partials(p_rz, cnt, sm), bb = reduce_partials(p_bb, cnt, sm + 4);
+    __shared__ double sm[32];
+    double rz = reduce_partials(p_rz, cnt, sm), bb = reduce_partials(p_bb, cnt, sm + 16);
     if (threadIdx.x == 0) {
         ctrl->val[V_RZ] = rz; ctrl->val[V_BNORM] = sqrt(bb);
         ctrl->cnt[C_PCG_DONE] = (bb == 0.0) ? 1 : 0;
@@ -832,7 +934,7 @@ __global__ __launch_bounds__(256) void k_pcg_update(int n, const Ctrl *__restric
                                                     const double *__restrict__ p, const double *__restrict__ Kp,
                                                     const double *__restrict__ dg, double *__restrict__ x, double *__restrict__ r,
                                                     double *__restrict__ z, double *__restrict__ p_rz, double *__restrict__ p_rr) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     if (ctrl->cnt[C_PCG_DONE]) return;
     const double pKp = reduce_partials(p_pKp, pcnt, sm);
     const double alpha = ctrl->val[V_RZ] / pKp;
@@ -845,15 +947,15 @@ __global__ __launch_bounds__(256) void k_pcg_update(int n, const Ctrl *__restric
         z[i] = zi;
         a += ri * zi; c += ri * ri;
     }
-    double ta = block_sum(a, sm), tc = block_sum(c, sm + 4);
+    double ta = block_sum(a, sm), tc = block_sum(c, sm + 16);
     if (threadIdx.x == 0) { p_rz[blockIdx.x] = ta; p_rr[blockIdx.x] = tc; }
 }
 // scalar step: convergence latch, beta, rz roll-over (single block)
 __global__ __launch_bounds__(256) void k_pcg_scalar(Ctrl *ctrl, const double *__restrict__ p_rz, const double *__restrict__ p_rr, int cnt,
                                                     double tol) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     if (ctrl->cnt[C_PCG_DONE]) return;
-    const double rz2 = reduce_partials(p_rz, cnt, sm), rr = reduce_partials(p_rr, cnt, sm + 4);
+    const double rz2 = reduce_partials(p_rz, cnt, sm), rr = reduce_partials(p_rr, cnt, sm + 16);
     if (threadIdx.x == 0) {
         ctrl->cnt[C_PCG_IT] += 1;
         if (sqrt(rr) <= tol * ctrl->val[V_BNORM] || !(rr == rr)) ctrl->cnt[C_PCG_DONE] = 1;
@@ -977,13 +1079,13 @@ __global__ __launch_bounds__(256) void k_ls_scan1(const Ctrl *__restrict__ ctrl,
 }
 // one block: a0, b0 from the partial sums (linesearch.c:19-25,119-120), exclusive scan of block totals
 __global__ __launch_bounds__(256) void k_ls_scan2(Ctrl *ctrl, const double *__restrict__ part, int pm, int pn, double *__restrict__ bt, int nblk) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     const double eta_m = reduce_partials(part + P_ETA_M * PGRID, pm, sm);
-    const double beta_m = reduce_partials(part + P_BETA_M * PGRID, pm, sm + 4);
+    const double beta_m = reduce_partials(part + P_BETA_M * PGRID, pm, sm + 16);
     const double ja = reduce_partials(part + P_A0 * PGRID, pm, sm);
-    const double jb = reduce_partials(part + P_B0 * PGRID, pm, sm + 4);
+    const double jb = reduce_partials(part + P_B0 * PGRID, pm, sm + 16);
     const double dxQdx = reduce_partials(part + P_DXQDX * PGRID, pn, sm);
-    const double dxdf = reduce_partials(part + P_DXDF * PGRID, pn, sm + 4);
+    const double dxdf = reduce_partials(part + P_DXDF * PGRID, pn, sm + 16);
     if (threadIdx.x == 0) {
         double eta = eta_m; eta += dxQdx; eta *= 0.5;
         double beta = beta_m; beta += dxdf; beta *= 0.5;
@@ -1028,7 +1130,7 @@ __global__ void k_ls_final(Ctrl *ctrl, const double *__restrict__ pa, const doub
 __global__ __launch_bounds__(256) void k_ls_prep_raw(int M2, const double *__restrict__ delta, const double *__restrict__ alpha,
                                                      u64 *__restrict__ key, u32 *__restrict__ idx, double *__restrict__ p_a0,
                                                      double *__restrict__ p_b0, Ctrl *ctrl) {
-    __shared__ double sm[8];
+    __shared__ double sm[32];
     double a0 = 0.0, b0 = 0.0; int nL = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M2; i += gridDim.x * blockDim.x) {
         const double dl = delta[i], al = alpha[i], t = al / dl;
@@ -1038,7 +1140,7 @@ __global__ __launch_bounds__(256) void k_ls_prep_raw(int M2, const double *__res
         if (L) nL++;
         if (L != P) { a0 += dl * dl; b0 += dl * al; }
     }
-    double t3 = block_sum(a0, sm), t4 = block_sum(b0, sm + 4);
+    double t3 = block_sum(a0, sm), t4 = block_sum(b0, sm + 16);
     int tn = block_sum_int(nL, (int *)sm);
     if (threadIdx.x == 0) { p_a0[blockIdx.x] = t3; p_b0[blockIdx.x] = t4; if (tn) atomicAdd(&ctrl->cnt[C_NL], tn); }
 }
@@ -1078,6 +1180,35 @@ static int upload_csr(QpdoDev *d, DevCsr *M, const QdevCsr *h) {
         HIPCHK(hipMemcpyAsync(M->val, h->val, (size_t)h->nnz * sizeof(double), hipMemcpyHostToDevice, d->stream));
     }
     M->tpr = pick_tpr(*M);
+    return 0;
+}
+static int read_ctrl(QpdoDev *d);
+// decide whether M streams from HBM (then use the LDS-staged kernel) and build its slab pointers
+static int setup_slabs(QpdoDev *d, DevCsr *M) {
+    const char *force = getenv("QPDO_SPMV");            // "slab" | "plain" | unset (auto)
+    const double bytes = 12.0 * (double)M->nnz;
+    bool want = bytes >= 192.0 * 1024 * 1024 && M->nrows >= 4096;   // beyond what L2 + Infinity Cache keep resident
+    if (force && !strcmp(force, "slab")) want = M->nrows >= 256;
+    if (force && !strcmp(force, "plain")) want = false;
+    M->use_slab = 0;
+    if (!want) return 0;
+    const int NWG = 256;                                 // one workgroup per CU
+    M->rows_per_wg = (M->nrows + NWG - 1) / NWG;
+    M->slab_grid = (M->nrows + M->rows_per_wg - 1) / M->rows_per_wg;
+    const long long lds_doubles = (160 * 1024 - 1024) / 8 - M->rows_per_wg;
+    if (lds_doubles < 1024) return 0;
+    int nslabs = (int)((M->ncols + lds_doubles - 1) / lds_doubles);
+    if (nslabs < 1) nslabs = 1;
+    int W = (M->ncols + nslabs - 1) / nslabs;
+    W = (W + 63) & ~63;
+    if (W > lds_doubles) { nslabs++; W = ((M->ncols + nslabs - 1) / nslabs + 63) & ~63; }
+    M->nslabs = nslabs; M->W = W;
+    int rc = dev_alloc(d, &M->sp, (size_t)M->nrows * (nslabs + 1));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ctrl_set_int, dim3(1), dim3(1), 0, d->stream, d->ctrl, C_VIOL, 0);
+    hipLaunchKernelGGL(k_build_slab_ptr, dim3(vgrid(M->nrows)), dim3(BLK), 0, d->stream, M->nrows, M->rp, M->ci, nslabs, W, M->sp, &d->ctrl->cnt[C_VIOL]);
+    rc = read_ctrl(d); if (rc) return rc;
+    M->use_slab = d->hctrl->cnt[C_VIOL] ? 0 : 1;          // unsorted rows: keep the plain kernel
     return 0;
 }
 static int read_ctrl(QpdoDev *d) {
@@ -1133,6 +1264,9 @@ int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *
         if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
         if (e != hipSuccess) rc = set_err(e, "upload", __LINE__);
     }
+    if (!rc) rc = setup_slabs(d, &d->Ar);
+    if (!rc) rc = setup_slabs(d, &d->At);
+    if (!rc) rc = setup_slabs(d, &d->Qf);
     if (rc) { qdev_destroy(d); return rc; }
     d->st.linsolve = 0;
     *out = d;
