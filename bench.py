@@ -9,7 +9,7 @@ the timed region starts (qpdo_setup uploads, converts and scales them; that time
 setup_s).  N > 1: independent QPs (different seeds) per rank, no data-path collective ("weak").
 
 Adds to the JSON line:
-  roofline     -- HBM roofline of the dominant kernel (the A' CSR SpMV inside PCG): algorithmic bytes
+  roofline     -- HBM roofline of the dominant kernel (the Q CSR SpMV inside PCG): algorithmic bytes
                   12 nnz + 4(rows+1) + 8 rows + 8 cols over the HIP-event duration sampled live in the timed solves.
   cpu_baseline -- the CPU oracle (a port; the reference needs CHOLMOD, absent here) timed on this host.
 """
@@ -123,7 +123,7 @@ def main():
         newton += stt["newton_passes"]; cg += stt["lin_iters"]
         iters += r["info"]["iterations"]; oters += r["info"]["oterations"]
         statuses.append(r["info"]["status_val"])
-        at_time += stt["spmv_At_avg_s"] * stt["spmv_At_samples"]; at_n += stt["spmv_At_samples"]
+        at_time += stt["spmv_Q_avg_s"] * stt["spmv_Q_samples"]; at_n += stt["spmv_Q_samples"]
     L.qpdo_amd_sync(s._w)
     barrier(dist)
     dt = time.time() - t0
@@ -132,16 +132,17 @@ def main():
 
     last = r
     rp, rd = problems.kkt_residuals(prob, last["x"], last["y"]) if last["info"]["status_val"] not in (-3, -4) else (None, None)
-    # roofline of the dominant kernel: A' SpMV (CSR n x m).  Live samples from the timed solves; a back-to-back
-    # micro-benchmark of the same kernel is reported beside it.
-    bench_t, alg_bytes = s.bench_spmv(1, reps=20)
+    # roofline of the dominant kernel: the Q product of the PCG operator (k_spmv_slab<EpiPcgQ>, full symmetric
+    # CSR n x n; the A and A' products of PCG only touch the active rows / columns, so Q carries the most bytes).
+    # Live HIP-event samples from the timed solves; a back-to-back micro-benchmark of the same kernel beside it.
+    bench_t, alg_bytes = s.bench_spmv(2, reps=20)
     live_t = at_time / at_n if at_n else bench_t
     achieved = alg_bytes / live_t / 1e9
-    roof = dict(bound="hbm", kernel="k_spmv_pcg<64,EpiPcgAt> (y = A' t, CSR n x m)", achieved=achieved, peak=HBM_PEAK_GBS,
+    roof = dict(bound="hbm", kernel="k_spmv_slab<EpiPcgQ> (Kp = Q p + sigma p, full symmetric CSR n x n)", achieved=achieved, peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None, alg_bytes_per_launch=alg_bytes,
                 avg_launch_s=live_t, samples=int(at_n), microbench_GBs=alg_bytes / bench_t / 1e9,
-                spmv_A_GBs=None, spmv_Q_GBs=None)
-    for which, key in ((0, "spmv_A_GBs"), (2, "spmv_Q_GBs")):
+                spmv_A_GBs=None, spmv_At_GBs=None)
+    for which, key in ((0, "spmv_A_GBs"), (1, "spmv_At_GBs")):
         t_, b_ = s.bench_spmv(which, reps=20)
         roof[key] = b_ / t_ / 1e9
     out = None

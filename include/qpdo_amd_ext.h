@@ -40,8 +40,8 @@ typedef struct {
     double spmv_alg_bytes;  /* sum over those launches of 12 nnz + 4(rows+1) + 8 rows + 8 cols */
     long   factor_count;    /* dense LDL' factorizations                                   */
     long   linsolve;        /* 0 pcg, 1 dense                                              */
-    double spmv_At_avg_s;   /* HIP-event average duration of the sampled A' SpMV inside PCG */
-    long   spmv_At_samples;
+    double spmv_Q_avg_s;    /* HIP-event average duration of the sampled Q SpMV inside PCG */
+    long   spmv_Q_samples;
 } QPDOAmdStats;
 
 int  qpdo_amd_device_count(void);

@@ -700,7 +700,7 @@ int qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out) {
     out->spmv_alg_bytes = (double)st.spmv_bytes;
     out->factor_count = (long)st.factor_count;
     out->linsolve = st.linsolve;
-    out->spmv_At_avg_s = avg;
-    out->spmv_At_samples = ns;
+    out->spmv_Q_avg_s = avg;
+    out->spmv_Q_samples = ns;
     return 0;
 }

@@ -107,7 +107,7 @@ int qdev_upload_vec(QpdoDev *d, int which, const double *src);
 int qdev_configure(QpdoDev *d, int linsolve /*0 pcg,1 dense,-1 auto*/, double pcg_tol, int pcg_maxit);
 int qdev_get_stats(QpdoDev *d, QdevStats *out);
 int qdev_reset_stats(QpdoDev *d);
-/* HIP-event average of the A' SpMV sampled once per PCG batch during the last solve */
+/* HIP-event average of the Q SpMV sampled once per PCG batch during the last solve */
 int qdev_get_spmv_sample(QpdoDev *d, double *avg_seconds, long *samples);
 
 /* micro-benchmark of the dominant kernel on the workspace's own matrices, timed with HIP

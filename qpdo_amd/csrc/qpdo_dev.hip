@@ -72,6 +72,9 @@ struct QpdoDev {
     int device = 0, n = 0, m = 0;
     hipStream_t stream = nullptr;
     DevCsr Ar, At, Qf;
+    DevCsr Atc;               // A' compacted to the weighted columns of the current Newton pass
+    int *row_cnt = nullptr; int compact = 1;
+    double *qdiag = nullptr; int qdiag_valid = 0;
     // n-vectors
     double *x, *xbar, *Qx, *Aty, *q, *df, *res_dual, *res_dual_in, *rhs, *dx, *Qdx, *Atdy, *D, *Dinv;
     double *pc_r, *pc_z, *pc_p, *pc_Kp, *pc_diag, *tmp_n;
@@ -549,6 +552,59 @@ __global__ void k_extract_diag(int n, const int *__restrict__ rp, const int *__r
         double dg = 0.0;
         for (int k = rp[r]; k < rp[r + 1]; k++) if (ci[k] == r) dg += val[k];
         out[r] = dg;
+    }
+}
+
+// ---- per-pass compaction of CSR(A') to the columns (constraints) that carry weight ------------------
+// Rows of A with d_i == 0 contribute exact zeros to A' (d .* (A p)); dropping those entries from the
+// n x m CSR once per Newton pass removes their HBM traffic from every PCG iteration.  Order inside a
+// row is preserved (stable ballot compaction), so the product stays reproducible.
+template <int TPR>
+__global__ __launch_bounds__(256) void k_count_flagged(int nrows, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                       const double *__restrict__ dw, int *__restrict__ cnt) {
+    const int lane = threadIdx.x % TPR;
+    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
+    const int ngroups = gridDim.x * (BLK / TPR);
+    for (int row = group; row < nrows; row += ngroups) {
+        int c = 0;
+        for (int k = rp[row] + lane; k < rp[row + 1]; k += TPR) c += (dw[ci[k]] != 0.0);
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1) c += __shfl_down(c, o, TPR);
+        if (lane == 0) cnt[row] = c;
+    }
+}
+// exclusive scan of cnt[0..n) into out[0..n] by one block (n up to a few 1e5)
+__global__ __launch_bounds__(1024) void k_scan_counts(const int *__restrict__ cnt, int n, int *__restrict__ out) {
+    __shared__ int sums[1024];
+    const int chunk = (n + 1023) / 1024;
+    const int beg = threadIdx.x * chunk, end = min(beg + chunk, n);
+    int s = 0;
+    for (int i = beg; i < end; i++) s += cnt[i];
+    sums[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; i++) { int t = sums[i]; sums[i] = run; run += t; } out[n] = run; }
+    __syncthreads();
+    int run = sums[threadIdx.x];
+    for (int i = beg; i < end; i++) { out[i] = run; run += cnt[i]; }
+}
+// one wave per row: stable compaction of (ci, val) pairs whose column weight is nonzero
+__global__ __launch_bounds__(256) void k_compact_rows(int nrows, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                      const double *__restrict__ val, const double *__restrict__ dw,
+                                                      const int *__restrict__ rp2, int *__restrict__ ci2, double *__restrict__ val2) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * BLK + threadIdx.x) >> 6;
+    const int nwaves = gridDim.x * (BLK >> 6);
+    for (int row = wave; row < nrows; row += nwaves) {
+        const int beg = rp[row], end = rp[row + 1];
+        int base = rp2[row];
+        for (int k0 = beg; k0 < end; k0 += 64) {
+            const int k = k0 + lane;
+            int c = 0; double v = 0.0; bool keep = false;
+            if (k < end) { c = ci[k]; v = val[k]; keep = dw[c] != 0.0; }
+            const u64 bal = __ballot(keep);
+            if (keep) { const int pos = base + __popcll(bal & ((1ull << lane) - 1ull)); ci2[pos] = c; val2[pos] = v; }
+            base += __popcll(bal);
+        }
     }
 }
 
@@ -1267,6 +1323,19 @@ int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *
     if (!rc) rc = setup_slabs(d, &d->Ar);
     if (!rc) rc = setup_slabs(d, &d->At);
     if (!rc) rc = setup_slabs(d, &d->Qf);
+    if (!rc) {   // compacted copy of A' shares the slab geometry of A'
+        const char *cm = getenv("QPDO_COMPACT");
+        d->compact = !(cm && !strcmp(cm, "0"));
+        d->Atc = d->At; d->Atc.rp = nullptr; d->Atc.ci = nullptr; d->Atc.val = nullptr; d->Atc.sp = nullptr;
+        if (d->compact) {
+            rc = dev_alloc(d, &d->Atc.rp, (size_t)n + 1);
+            if (!rc) rc = dev_alloc(d, &d->Atc.ci, (size_t)At->nnz);
+            if (!rc) rc = dev_alloc(d, &d->Atc.val, (size_t)At->nnz);
+            if (!rc && d->At.use_slab) rc = dev_alloc(d, &d->Atc.sp, (size_t)n * (d->At.nslabs + 1));
+            if (!rc) rc = dev_alloc(d, &d->row_cnt, (size_t)n);
+        }
+        if (!rc) rc = dev_alloc(d, &d->qdiag, (size_t)n);
+    }
     if (rc) { qdev_destroy(d); return rc; }
     d->st.linsolve = 0;
     *out = d;
@@ -1322,6 +1391,7 @@ int qdev_scale_data(QpdoDev *d, int iters, int use_Qx, double *D_host, double *E
     }
     const int gQ = spmv_grid(d->Qf, d->Qf.tpr, false);
     DISPATCH_TPR(d->Qf, k_scale_sym, gQ, n, d->Qf.rp, d->Qf.ci, d->Qf.val, (const double *)d->D);
+    d->qdiag_valid = 0;
     LAUNCH(k_mul, vgrid(n), n, d->D, d->q, d->q);                    // q <- D q
     // cost scaling: c = 1 / max(1, ||Qx + q||inf)
     LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
@@ -1375,6 +1445,7 @@ int qdev_download_q(QpdoDev *d, double *q) {
 }
 int qdev_scale_Q_values(QpdoDev *d, double factor) {
     HIPCHK(hipSetDevice(d->device));
+    d->qdiag_valid = 0;
     if (d->Qf.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qf.nnz, d->Qf.val, factor);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1484,30 +1555,49 @@ int qdev_residuals(QpdoDev *d, int proximal, double sigma, QdevResid *out) {
 }
 
 // ---- linear solve -----------------------------------------------------------------------------------
+// build Atc for the current weights d (once per Newton pass)
+static int compact_At(QpdoDev *d) {
+    const int n = d->n;
+    const DevCsr &M = d->At;
+    const int g = spmv_grid(M, M.tpr, false) > 4096 ? 4096 : (M.use_slab ? 2048 : spmv_grid(M, M.tpr, false));
+    DISPATCH_TPR(M, k_count_flagged, g, n, M.rp, M.ci, (const double *)d->d, d->row_cnt);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d->stream, d->row_cnt, n, d->Atc.rp);
+    LAUNCH(k_compact_rows, 2048, n, M.rp, M.ci, M.val, (const double *)d->d, (const int *)d->Atc.rp, d->Atc.ci, d->Atc.val);
+    if (M.use_slab)
+        LAUNCH(k_build_slab_ptr, vgrid(n), n, d->Atc.rp, d->Atc.ci, M.nslabs, M.W, d->Atc.sp, &d->ctrl->cnt[C_VIOL]);
+    int nnz2 = 0;
+    HIPCHK(hipMemcpyAsync(&nnz2, d->Atc.rp + n, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    d->Atc.nnz = nnz2;
+    return 0;
+}
 static int pcg_solve(QpdoDev *d, int *iters_out) {
     const int n = d->n;
-    const int gq = spmv_grid(d->Qf, d->Qf.tpr, false);
-    // Jacobi diagonal
-    LAUNCH(k_extract_diag, vgrid(n), n, d->Qf.rp, d->Qf.ci, d->Qf.val, d->tmp_n);
-    (void)gq;
-    const int gAt = spmv_grid(d->At, d->At.tpr, false);
-    DISPATCH_TPR(d->At, k_jacobi_diag, gAt, n, d->At.rp, d->At.ci, d->At.val, (const double *)d->d, (const double *)d->tmp_n, d->sigma_f, d->pc_diag);
+    if (!d->qdiag_valid) {
+        LAUNCH(k_extract_diag, vgrid(n), n, d->Qf.rp, d->Qf.ci, d->Qf.val, d->qdiag);
+        d->qdiag_valid = 1;
+    }
+    const DevCsr *AtP = &d->At;
+    if (d->compact) { int rc = compact_At(d); if (rc) return rc; AtP = &d->Atc; }
+    // Jacobi diagonal: Q_jj + sigma_f + sum_i A_ij^2 d_i
+    const int gAt = d->At.use_slab ? 2048 : spmv_grid(d->At, d->At.tpr, false);
+    DISPATCH_TPR(d->At, k_jacobi_diag, gAt, n, AtP->rp, AtP->ci, AtP->val, (const double *)d->d, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
     const int g = vgrid(n);
     double *P = d->part;
     LAUNCH(k_pcg_init, g, n, d->rhs, d->pc_diag, d->dx, d->pc_r, d->pc_z, d->pc_p, P + P_RZ * PGRID, P + P_RR * PGRID);
     LAUNCH(k_pcg_init2, 1, P + P_RZ * PGRID, P + P_RR * PGRID, g, d->ctrl);
-    const int pAt = spmv_pgrid(d->At);
+    const int pAt = spmv_pgrid(*AtP);
     int it = 0;
     while (it < d->pcg_maxit) {
         const int it_before = it;
         int batch = d->pcg_batch; if (it + batch > d->pcg_maxit) batch = d->pcg_maxit - it;
         for (int b = 0; b < batch; b++) {
             launch_spmv_pcg(d, d->Ar, d->pc_p, EpiPcgA{d->d, d->pc_t, nullptr}, false);
-            launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQ{d->pc_p, d->sigma_f, d->pc_Kp}, false);
             const bool sample = (b == 0);
             if (sample) hipEventRecord(d->ev0, d->stream);
-            launch_spmv_pcg(d, d->At, d->pc_t, EpiPcgAt{d->pc_p, d->pc_Kp, P + P_PKP * PGRID}, true);
+            launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQ{d->pc_p, d->sigma_f, d->pc_Kp}, false);
             if (sample) hipEventRecord(d->ev1, d->stream);
+            launch_spmv_pcg(d, *AtP, d->pc_t, EpiPcgAt{d->pc_p, d->pc_Kp, P + P_PKP * PGRID}, true);
             LAUNCH(k_pcg_update, g, n, d->ctrl, P + P_PKP * PGRID, pAt, d->pc_p, d->pc_Kp, d->pc_diag, d->dx, d->pc_r, d->pc_z,
                    P + P_RZ * PGRID, P + P_RR * PGRID);
             LAUNCH(k_pcg_scalar, 1, d->ctrl, P + P_RZ * PGRID, P + P_RR * PGRID, g, d->pcg_tol);
