@@ -533,7 +533,7 @@ void qpdo_solve(QPDOWorkspace *work) {
             else if (r.n_active) branch = 1;
             else branch = 2;
             int lin = 0;
-            DEVCALL(qdev_newton_step(dev, branch, prox, work->sigma, &work->tau, &lin));
+            DEVCALL(qdev_newton_step(dev, branch, r.n_enter + r.n_leave, prox, work->sigma, &work->tau, &lin));
             be->newton_passes++;
             if (tr) { tr->tau = work->tau; tr->n_active = r.n_active; tr->n_enter = r.n_enter; tr->n_leave = r.n_leave; tr->factor_branch = branch; tr->lin_iters = lin; }
         }

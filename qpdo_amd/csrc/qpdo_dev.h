@@ -79,7 +79,7 @@ int qdev_residuals(QpdoDev *d, int proximal, double sigma, QdevResid *out);
 
 /* one Newton step (iteration.c:11-25): factor-state update, direction, exact linesearch,
  * iterate update.  branch: 0 full (d = active/mu), 1 rank update (enter/leave), 2 Q only. */
-int qdev_newton_step(QpdoDev *d, int branch, int proximal, double sigma,
+int qdev_newton_step(QpdoDev *d, int branch, int n_changed /* n_enter + n_leave */, int proximal, double sigma,
                      double *tau_out, int *lin_iters_out);
 
 /* outer-update helpers */

@@ -75,6 +75,10 @@ struct QpdoDev {
     DevCsr Atc;               // A' compacted to the weighted columns of the current Newton pass
     int *row_cnt = nullptr; int compact = 1;
     double *qdiag = nullptr; int qdiag_valid = 0;
+    // dense direct solver
+    int dense_ld = 0, dense_nblk = 0, dense_max_n = 16384; int dense_valid = 0;
+    double *Kd = nullptr, *Wd = nullptr, *Dg = nullptr, *dz = nullptr, *dxw = nullptr;
+    int dense_last_branch = -1; double dense_last_sigma = -1.0;
     // n-vectors
     double *x, *xbar, *Qx, *Aty, *q, *df, *res_dual, *res_dual_in, *rhs, *dx, *Qdx, *Atdy, *D, *Dinv;
     double *pc_r, *pc_z, *pc_p, *pc_Kp, *pc_diag, *tmp_n;
@@ -1203,6 +1207,201 @@ __global__ __launch_bounds__(256) void k_ls_prep_raw(int M2, const double *__res
 __global__ void k_set_partial(double *p, double v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
 __global__ void k_ctrl_set_int(Ctrl *c, int slot, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) c->cnt[slot] = v; }
 
+
+// ================================================================================================
+// Dense direct solver for K = Q + sigma_f I + A' diag(d) A  (reference N2/N4: cholmod_interface.c:8-52,
+// 98-102).  With CHOLMOD's natural ordering and percent-level fill the normal-equations term is
+// structurally dense, i.e. the supernodal factorization degenerates to ONE dense front of order n;
+// this is that front: blocked right-looking LDL' (no pivoting, as CHOLMOD_LDLt on an SPD matrix) whose
+// trailing update runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).  Used when n <= dense_max_n.
+// Storage: column-major lower triangle K[i + j*ld], ld = n rounded up to 64; the padding carries an
+// identity so every block is full.  W (ld x 64) holds the scaled panel L*D of the current step.
+// ================================================================================================
+static const int DNB = 64;
+typedef double dvec4 __attribute__((ext_vector_type(4)));
+
+// one wave per column j: acc (LDS, n doubles) gathers Q(:,j) and sum_r d_r a_rj a_r(:) for rows >= j.
+// Sequential over r inside the wave, so the summation order is fixed (reproducible).
+__global__ __launch_bounds__(64) void k_dense_assemble(int n, int ld, const int *__restrict__ qrp, const int *__restrict__ qci,
+                                                       const double *__restrict__ qval, const int *__restrict__ trp,
+                                                       const int *__restrict__ tci, const double *__restrict__ tval,
+                                                       const int *__restrict__ arp, const int *__restrict__ aci,
+                                                       const double *__restrict__ aval, const double *__restrict__ dw,
+                                                       double sigma_f, double *__restrict__ K) {
+    extern __shared__ __attribute__((aligned(16))) double acc[];
+    const int lane = threadIdx.x;
+    for (int j = blockIdx.x; j < ld; j += gridDim.x) {
+        double *col = K + (size_t)j * ld;
+        if (j >= n) {                                  // identity padding
+            for (int i = j + lane; i < ld; i += 64) col[i] = (i == j) ? 1.0 : 0.0;
+            continue;
+        }
+        for (int i = j + lane; i < n; i += 64) acc[i] = 0.0;
+        __syncthreads();
+        for (int k = qrp[j] + lane; k < qrp[j + 1]; k += 64) { const int i = qci[k]; if (i >= j) acc[i] += qval[k]; }
+        __syncthreads();
+        for (int t = trp[j]; t < trp[j + 1]; t++) {
+            const int r = tci[t];
+            const double wgt = dw[r];
+            if (wgt == 0.0) continue;
+            const double w = wgt * tval[t];
+            for (int e = arp[r] + lane; e < arp[r + 1]; e += 64) { const int i = aci[e]; if (i >= j) acc[i] += w * aval[e]; }
+            __syncthreads();                           // one wave: orders the LDS read-modify-writes of consecutive rows
+        }
+        __syncthreads();
+        if (lane == 0) acc[j] += sigma_f;
+        __syncthreads();
+        for (int i = j + lane; i < ld; i += 64) col[i] = (i < n) ? acc[i] : 0.0;
+    }
+}
+// LDL' of the 64x64 diagonal block kb in LDS; writes unit-lower L back and D to Dg
+__global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ K, int ld, int kb, double *__restrict__ Dg) {
+    __shared__ double a[DNB][DNB + 1];
+    __shared__ double colv[DNB];
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
+    for (int idx = tid; idx < DNB * DNB; idx += 256) { const int r = idx % DNB, c = idx / DNB; a[r][c] = K[base + r + (size_t)c * ld]; }
+    __syncthreads();
+    for (int j = 0; j < DNB; j++) {
+        const double dj = a[j][j];
+        if (tid > j && tid < DNB) colv[tid] = a[tid][j];           // v_i = l_ij d_j
+        __syncthreads();
+        // trailing update of the lower triangle: a_ic -= v_i v_c / d_j  for j < c <= i
+        const int t = DNB - 1 - j;
+        for (int idx = tid; idx < t * t; idx += 256) {
+            const int i = j + 1 + idx / t, c = j + 1 + idx % t;
+            if (c <= i) a[i][c] -= colv[i] * (colv[c] / dj);
+        }
+        if (tid > j && tid < DNB) a[tid][j] = colv[tid] / dj;
+        __syncthreads();
+    }
+    for (int idx = tid; idx < DNB * DNB; idx += 256) {
+        const int r = idx % DNB, c = idx / DNB;
+        if (r > c) K[base + r + (size_t)c * ld] = a[r][c];
+    }
+    if (tid < DNB) Dg[kb * DNB + tid] = a[tid][tid];
+}
+// panel below the diagonal block: X L_kk' = A  =>  W = X (= L D), L = X / D.  One thread per row.
+__global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ K, int ld, int kb, const double *__restrict__ Dg,
+                                                   double *__restrict__ W) {
+    __shared__ double L[DNB][DNB + 1];
+    __shared__ double dinv[DNB];
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
+    for (int idx = tid; idx < DNB * DNB; idx += 256) { const int r = idx % DNB, c = idx / DNB; L[r][c] = (r > c) ? K[base + r + (size_t)c * ld] : 0.0; }
+    if (tid < DNB) dinv[tid] = 1.0 / Dg[kb * DNB + tid];
+    __syncthreads();
+    const int r = (kb + 1) * DNB + blockIdx.x * 256 + tid;
+    if (r >= ld) return;
+    double x[DNB];
+    double *row = K + r + (size_t)kb * DNB * ld;
+#pragma unroll
+    for (int c = 0; c < DNB; c++) x[c] = row[(size_t)c * ld];
+#pragma unroll
+    for (int c = 0; c < DNB; c++) {
+        double sacc = x[c];
+#pragma unroll
+        for (int cp = 0; cp < c; cp++) sacc -= x[cp] * L[c][cp];
+        x[c] = sacc;
+    }
+#pragma unroll
+    for (int c = 0; c < DNB; c++) { W[r + (size_t)c * ld] = x[c]; row[(size_t)c * ld] = x[c] * dinv[c]; }
+}
+// trailing update on the matrix cores: C(ti,tj) -= W(ti) * L(tj)'  for kb < tj <= ti.
+// 4 waves, each a 32x32 quadrant as 2x2 tiles of v_mfma_f64_16x16x4_f64.
+// A/B lane map: lane l holds A[l&15][k = l>>4], B[k = l>>4][l&15]; C/D: row = (l>>4) + 4*reg, col = l&15.
+__global__ __launch_bounds__(256) void k_ldl_syrk(double *__restrict__ K, int ld, int kb, const double *__restrict__ W) {
+    const int ti = kb + 1 + blockIdx.x, tj = kb + 1 + blockIdx.y;
+    if (tj > ti) return;
+    __shared__ double As[DNB][80];      // [k][row]; row stride 80 doubles keeps the two k-rows of a half-wave on disjoint banks
+    __shared__ double Bs[DNB][80];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < DNB * DNB; idx += 256) {
+        const int r = idx % DNB, k = idx / DNB;
+        As[k][r] = W[(size_t)ti * DNB + r + (size_t)k * ld];
+        Bs[k][r] = K[(size_t)tj * DNB + r + ((size_t)kb * DNB + k) * ld];
+    }
+    __syncthreads();
+    const int wave = tid >> 6, l = tid & 63;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const int li = l & 15, lk = l >> 4;
+    dvec4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) acc[m][q] = (dvec4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < DNB; k0 += 4) {
+        const double a0 = As[k0 + lk][wr + li], a1 = As[k0 + lk][wr + 16 + li];
+        const double b0 = Bs[k0 + lk][wc + li], b1 = Bs[k0 + lk][wc + 16 + li];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int row = wr + m * 16 + lk + 4 * v, col = wc + q * 16 + li;
+                double *c = K + (size_t)ti * DNB + row + ((size_t)tj * DNB + col) * ld;
+                *c = *c - acc[m][q][v];
+            }
+}
+// forward step kb: every wave re-solves the unit-lower diagonal block for z_k (cheap), wave 0 publishes it,
+// then wave b updates the 64 rows of block kb+1+b:  x_i -= L(i, kb) z_k.
+__global__ __launch_bounds__(64) void k_ldl_fwd(const double *__restrict__ K, int ld, int kb, double *__restrict__ x, double *__restrict__ z) {
+    __shared__ double zs[DNB];
+    const int l = threadIdx.x;
+    const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
+    double v = x[kb * DNB + l];
+    for (int c = 0; c < DNB - 1; c++) {
+        const double zc = __shfl(v, c, 64);
+        if (l > c) v -= K[base + l + (size_t)c * ld] * zc;
+    }
+    zs[l] = v;
+    if (blockIdx.x == 0) z[kb * DNB + l] = v;
+    __syncthreads();
+    const int r = (kb + 1 + blockIdx.x) * DNB + l;
+    if (r >= ld) return;
+    const double *row = K + r + (size_t)kb * DNB * ld;
+    double sacc = x[r];
+    for (int c = 0; c < DNB; c++) sacc -= row[(size_t)c * ld] * zs[c];
+    x[r] = sacc;
+}
+// backward step kb: solve L_kk' x_k = y_k (y = z ./ D already folded in by the caller), publish x_k,
+// then wave j (< kb) updates y_j -= L(kb, j)' x_k through an LDS transpose of the 64x64 tile.
+__global__ __launch_bounds__(64) void k_ldl_bwd(const double *__restrict__ K, int ld, int kb, double *__restrict__ y, double *__restrict__ xout) {
+    __shared__ double xs[DNB];
+    __shared__ double tile[DNB][DNB + 1];
+    const int l = threadIdx.x;
+    const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
+    double v = y[kb * DNB + l];
+    for (int c = DNB - 1; c > 0; c--) {                 // x_c final; rows l < c subtract L[c][l] x_c
+        const double xc = __shfl(v, c, 64);
+        if (l < c) v -= K[base + c + (size_t)l * ld] * xc;
+    }
+    xs[l] = v;
+    if (blockIdx.x == 0) xout[kb * DNB + l] = v;
+    __syncthreads();
+    if (kb == 0) return;
+    const int j = blockIdx.x;                            // 0 .. kb-1
+    if (j >= kb) return;
+    for (int c = 0; c < DNB; c++) tile[l][c] = K[(size_t)kb * DNB + l + ((size_t)j * DNB + c) * ld];   // rows contiguous across lanes
+    __syncthreads();
+    double sacc = y[j * DNB + l];
+    for (int r = 0; r < DNB; r++) sacc -= tile[r][l] * xs[r];
+    y[j * DNB + l] = sacc;
+}
+__global__ void k_dense_load_rhs(int n, int ld, const double *__restrict__ b, double *__restrict__ x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ld; i += gridDim.x * blockDim.x) x[i] = i < n ? b[i] : 0.0;
+}
+__global__ void k_dense_scale_d(int ld, const double *__restrict__ z, const double *__restrict__ Dg, double *__restrict__ y) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ld; i += gridDim.x * blockDim.x) y[i] = z[i] / Dg[i];
+}
+
 // ================================================================================================
 // host side of the backend
 // ================================================================================================
@@ -1356,7 +1555,12 @@ void qdev_destroy(QpdoDev *d) {
 int qdev_sync(QpdoDev *d) { HIPCHK(hipSetDevice(d->device)); HIPCHK(hipStreamSynchronize(d->stream)); return 0; }
 
 int qdev_configure(QpdoDev *d, int linsolve, double pcg_tol, int pcg_maxit) {
+    const char *mx = getenv("QPDO_DENSE_MAX_N");
+    if (mx && *mx) d->dense_max_n = atoi(mx);
+    if (d->dense_max_n > 18000) d->dense_max_n = 18000;       // the assembly accumulator (n doubles) must fit in LDS
     if (linsolve >= 0) d->linsolve = linsolve;
+    else d->linsolve = (d->n <= d->dense_max_n) ? 1 : 0;
+    if (d->linsolve == 1 && d->n > 18000) d->linsolve = 0;
     if (pcg_tol > 0) d->pcg_tol = pcg_tol;
     if (pcg_maxit > 0) d->pcg_maxit = pcg_maxit;
     d->st.linsolve = d->linsolve;
@@ -1391,7 +1595,7 @@ int qdev_scale_data(QpdoDev *d, int iters, int use_Qx, double *D_host, double *E
     }
     const int gQ = spmv_grid(d->Qf, d->Qf.tpr, false);
     DISPATCH_TPR(d->Qf, k_scale_sym, gQ, n, d->Qf.rp, d->Qf.ci, d->Qf.val, (const double *)d->D);
-    d->qdiag_valid = 0;
+    d->qdiag_valid = 0; d->dense_valid = 0;
     LAUNCH(k_mul, vgrid(n), n, d->D, d->q, d->q);                    // q <- D q
     // cost scaling: c = 1 / max(1, ||Qx + q||inf)
     LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
@@ -1445,7 +1649,7 @@ int qdev_download_q(QpdoDev *d, double *q) {
 }
 int qdev_scale_Q_values(QpdoDev *d, double factor) {
     HIPCHK(hipSetDevice(d->device));
-    d->qdiag_valid = 0;
+    d->qdiag_valid = 0; d->dense_valid = 0;
     if (d->Qf.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qf.nnz, d->Qf.val, factor);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1615,6 +1819,55 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
     return 0;
 }
 
+// ---- dense direct solve ------------------------------------------------------------------------------
+static int dense_alloc(QpdoDev *d) {
+    if (d->Kd) return 0;
+    const int ld = (d->n + DNB - 1) / DNB * DNB;
+    d->dense_ld = ld; d->dense_nblk = ld / DNB;
+    int rc = dev_alloc(d, &d->Kd, (size_t)ld * ld);
+    if (!rc) rc = dev_alloc(d, &d->Wd, (size_t)ld * DNB);
+    if (!rc) rc = dev_alloc(d, &d->Dg, (size_t)ld);
+    if (!rc) rc = dev_alloc(d, &d->dz, (size_t)ld);
+    if (!rc) rc = dev_alloc(d, &d->dxw, (size_t)ld);
+    if (!rc) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (e != hipSuccess) rc = set_err(e, "hipFuncSetAttribute", __LINE__);
+    }
+    return rc;
+}
+static int dense_factor(QpdoDev *d) {
+    int rc = dense_alloc(d); if (rc) return rc;
+    const int n = d->n, ld = d->dense_ld, nb = d->dense_nblk;
+    const int g = ld < 1024 ? ld : 1024;
+    hipLaunchKernelGGL(k_dense_assemble, dim3(g), dim3(64), (size_t)n * sizeof(double), d->stream, n, ld, d->Qf.rp, d->Qf.ci, d->Qf.val,
+                       d->At.rp, d->At.ci, d->At.val, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)d->d, d->sigma_f, d->Kd);
+    for (int kb = 0; kb < nb; kb++) {
+        hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), 0, d->stream, d->Kd, ld, kb, d->Dg);
+        const int below = nb - kb - 1;
+        if (below > 0) {
+            hipLaunchKernelGGL(k_ldl_panel, dim3((below * DNB + 255) / 256), dim3(256), 0, d->stream, d->Kd, ld, kb, (const double *)d->Dg, d->Wd);
+            hipLaunchKernelGGL(k_ldl_syrk, dim3(below, below), dim3(256), 0, d->stream, d->Kd, ld, kb, (const double *)d->Wd);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    d->dense_valid = 1;
+    d->st.factor_count++;
+    return 0;
+}
+static int dense_solve(QpdoDev *d) {
+    const int n = d->n, ld = d->dense_ld, nb = d->dense_nblk;
+    LAUNCH(k_dense_load_rhs, vgrid(ld), n, ld, (const double *)d->rhs, d->dxw);
+    for (int kb = 0; kb < nb; kb++) {
+        const int below = nb - kb - 1;
+        hipLaunchKernelGGL(k_ldl_fwd, dim3(below > 0 ? below : 1), dim3(64), 0, d->stream, (const double *)d->Kd, ld, kb, d->dxw, d->dz);
+    }
+    LAUNCH(k_dense_scale_d, vgrid(ld), ld, (const double *)d->dz, (const double *)d->Dg, d->dz);
+    for (int kb = nb - 1; kb >= 0; kb--)
+        hipLaunchKernelGGL(k_ldl_bwd, dim3(kb > 0 ? kb : 1), dim3(64), 0, d->stream, (const double *)d->Kd, ld, kb, d->dz, d->dxw);
+    HIPCHK(hipMemcpyAsync(d->dx, d->dxw, (size_t)n * 8, hipMemcpyDeviceToDevice, d->stream));
+    return 0;
+}
+
 // ---- linesearch sort + scan + search (shared by the Newton step and the parity entry point) -----------
 static int linesearch_device(QpdoDev *d, int pm, int pn) {
     const int M2 = 2 * d->m;
@@ -1637,14 +1890,26 @@ static int linesearch_device(QpdoDev *d, int pm, int pn) {
 }
 
 // ---- one Newton step (iteration.c:11-25) ----------------------------------------------------------------
-int qdev_newton_step(QpdoDev *d, int branch, int proximal, double sigma, double *tau_out, int *lin_iters_out) {
+int qdev_newton_step(QpdoDev *d, int branch, int n_changed, int proximal, double sigma, double *tau_out, int *lin_iters_out) {
     HIPCHK(hipSetDevice(d->device));
     const int n = d->n, m = d->m;
     if (branch == 0 || branch == 2) d->sigma_f = proximal ? sigma : 0.0;     // ldlchol beta (cholmod_interface.c:11-13)
     LAUNCH(k_newton_prep, vgrid(m), m, branch, d->active, d->active_old, d->isq, d->mu, d->res_prim_in, d->d, d->dy);
     launch_spmv(d, d->At, d->dy, EpiRhs{d->res_dual_in, d->Atdy, d->rhs}, false);
-    int lin = 0;
-    int rc = pcg_solve(d, &lin); if (rc) return rc;
+    int lin = 0, rc = 0;
+    // the dense factor stays valid only while (sigma_f, d) is unchanged: full refactor (0) always rebuilds,
+    // rank update (1) changes d iff rows entered or left, Q-only (2) is unchanged if the previous factor
+    // was also Q-only at the same sigma
+    if (branch == 0) d->dense_valid = 0;
+    else if (branch == 1) { if (n_changed > 0) d->dense_valid = 0; }
+    else if (!(d->dense_last_branch == 2 && d->dense_last_sigma == d->sigma_f)) d->dense_valid = 0;
+    if (d->linsolve == 1) {
+        if (!d->dense_valid) { rc = dense_factor(d); if (rc) return rc; }
+        rc = dense_solve(d); if (rc) return rc;
+    } else {
+        rc = pcg_solve(d, &lin); if (rc) return rc;
+    }
+    d->dense_last_branch = branch; d->dense_last_sigma = d->sigma_f;
     d->st.lin_iters += lin;
     *lin_iters_out = lin;
     // Qdx (+ sigma dx), n-side dots
@@ -1737,6 +2002,7 @@ int qdev_update_mu(QpdoDev *d, double eps_abs, double theta, double delta, doubl
 int qdev_mu_changed_update(QpdoDev *d) {
     HIPCHK(hipSetDevice(d->device));
     LAUNCH(k_mu_changed_d, vgrid(d->m), d->m, d->mu_changed, d->at_scale, d->isq, d->d);
+    d->dense_valid = 0;
     HIPCHK(hipGetLastError());
     return 0;
 }

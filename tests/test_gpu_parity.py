@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 GOLD = load_golden()
 
 
+@pytest.fixture(params=["dense", "pcg"])
+def linsolve(request, monkeypatch):
+    """both device linear solvers: dense MFMA LDL' (default for n <= 16384) and Jacobi-PCG"""
+    monkeypatch.setenv("QPDO_LINSOLVE", request.param)
+    return request.param
+
+
 def assert_same_outcome(res, ref_info, ref_x, ref_y, prob=None):
     i = res["info"]
     assert i["status_val"] == ref_info["status_val"]
@@ -27,10 +34,11 @@ def assert_same_outcome(res, ref_info, ref_x, ref_y, prob=None):
 
 
 @pytest.mark.parametrize("name", sorted(GOLD))
-def test_against_golden_vectors(name, gpu_required):
+def test_against_golden_vectors(name, linsolve, gpu_required):
     g = GOLD[name]
     p = golden_problem(g["spec"])
     r = solver.solve_problem(p, verbose=0, **g["settings"])
+    assert r["stats"]["linsolve"] == (1 if linsolve == "dense" else 0)
     assert_same_outcome(r, g, g["x"], g["y"], p)
     assert [t["kind"] for t in r["trace"]] == g["kinds"]
     assert [t["n_active"] for t in r["trace"]] == g["n_active"]
@@ -58,7 +66,7 @@ def test_reference_known_answers_on_device(case, gpu_required):
     (28, 500, 1000, 0.02, 0, dict(eps_abs=1e-8)),
     (29, 200, 400, 0.05, 0, dict(reset_newton_iter=3, inner_max_iter=6)),
 ])
-def test_random_instances_match_live_oracle(seed, n, m, dens, neq, st, gpu_required):
+def test_random_instances_match_live_oracle(seed, n, m, dens, neq, st, linsolve, gpu_required):
     p = problems.random_qp(seed, n, m, dens, neq)
     o = ob.OracleSolver(p, ob.default_settings(**st))
     ro = o.solve()
@@ -128,7 +136,7 @@ def test_linesearch_matches_oracle(m, gpu_required):
     s.delete()
 
 
-def test_warm_start_and_update_sequence_matches_oracle(gpu_required):
+def test_warm_start_and_update_sequence_matches_oracle(linsolve, gpu_required):
     p = problems.config_qp("C1")
     o = ob.OracleSolver(p, ob.default_settings())
     s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0)
@@ -173,6 +181,18 @@ def test_max_iter_and_max_time_statuses(gpu_required):
     assert r["info"]["status_val"] == -5 and r["info"]["iterations"] == 3
     r = solver.solve_problem(p, verbose=0, max_time=1e-9)
     assert r["info"]["status_val"] == -6
+
+
+def test_dense_factor_is_reused_when_weights_do_not_change(gpu_required, monkeypatch):
+    """consecutive passes with an unchanged active set must not refactor (reference: no update at all,
+    src/newton.c:25-30)"""
+    monkeypatch.setenv("QPDO_LINSOLVE", "dense")
+    p = problems.config_qp("C1")
+    r = solver.solve_problem(p, verbose=0)
+    newton = [t for t in r["trace"] if t["kind"] == 0]
+    unchanged = sum(1 for t in newton if t["factor_branch"] == 1 and t["n_enter"] + t["n_leave"] == 0)
+    assert r["stats"]["factor_count"] <= len(newton) - unchanged
+    assert r["stats"]["factor_count"] >= 1 and r["stats"]["lin_iters"] == 0
 
 
 def test_config2_full_size_properties(gpu_required):
