@@ -142,6 +142,16 @@ def main():
                 unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None, alg_bytes_per_launch=alg_bytes,
                 avg_launch_s=live_t, samples=int(at_n), microbench_GBs=alg_bytes / bench_t / 1e9,
                 spmv_A_GBs=None, spmv_At_GBs=None)
+    # HBM bytes per launch from the PMC counters cannot be collected inside this process; the figure comes from
+    # the committed rocprofv3 --pmc passes on the same workload and kernel (profiles/r01_pmc_spmv_c4.json), if present
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_spmv_c4.json")) as fh:
+            pmc = json.load(fh)
+        if a.workload == "C4":
+            roof["traffic"] = pmc["Q  (CSR n x n)"]["traffic_bytes"]
+            roof["traffic_source"] = "profiles/r01_pmc_spmv_c4.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+    except Exception:
+        pass
     for which, key in ((0, "spmv_A_GBs"), (1, "spmv_At_GBs")):
         t_, b_ = s.bench_spmv(which, reps=20)
         roof[key] = b_ / t_ / 1e9

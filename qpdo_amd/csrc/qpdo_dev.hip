@@ -75,6 +75,9 @@ struct QpdoDev {
     DevCsr Atc;               // A' compacted to the weighted columns of the current Newton pass
     int *row_cnt = nullptr; int compact = 1;
     double *qdiag = nullptr; int qdiag_valid = 0;
+    // heavy-row deflation
+    int deflate = 1, defl_r = 0, max_row_nnz_A = 0; DevCsr Ath; int *defl_hist = nullptr, *defl_list = nullptr, *defl_count = nullptr;
+    double *defl_flag = nullptr, *defl_t = nullptr, *defl_S = nullptr, *defl_Sinv = nullptr, *defl_v = nullptr; long long defl_passes = 0;
     // dense direct solver
     int dense_ld = 0, dense_nblk = 0, dense_max_n = 16384; int dense_valid = 0;
     double *Kd = nullptr, *Wd = nullptr, *Dg = nullptr, *dz = nullptr, *dxw = nullptr;
@@ -550,6 +553,26 @@ __global__ __launch_bounds__(256) void k_jacobi_diag(int n, const int *__restric
         if (lane == 0) out[row] = qdiag[row] + sigma_f + s;
     }
 }
+// deflated variant: P_j = max(remainder_j, 1e-6 * full_j).  The floor bounds the cancellation in the Woodbury
+// form u - P^-1 A_h' S^-1 A_h u to six digits; M = P + A_h' D_h A_h stays SPD, which is all PCG requires.
+template <int TPR>
+__global__ __launch_bounds__(256) void k_jacobi_diag2(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                      const double *__restrict__ val, const double *__restrict__ dlight,
+                                                      const double *__restrict__ dfull, const double *__restrict__ qdiag,
+                                                      double sigma_f, double *__restrict__ out) {
+    const int lane = threadIdx.x % TPR;
+    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
+    const int ngroups = gridDim.x * (BLK / TPR);
+    for (int row = group; row < n; row += ngroups) {
+        double s = 0.0, f = 0.0;
+        for (int k = rp[row] + lane; k < rp[row + 1]; k += TPR) { const double v = val[k]; const int c = ci[k]; s += v * v * dlight[c]; f += v * v * dfull[c]; }
+        s = group_sum<TPR>(s); f = group_sum<TPR>(f);
+        if (lane == 0) {
+            const double rem = qdiag[row] + sigma_f + s, full = qdiag[row] + sigma_f + f;
+            out[row] = rem > 1e-6 * full ? rem : 1e-6 * full;
+        }
+    }
+}
 __global__ void k_extract_diag(int n, const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
                                double *__restrict__ out) {
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
@@ -980,9 +1003,9 @@ __global__ __launch_bounds__(256) void k_pcg_init(int n, const double *__restric
     double ta = block_sum(a, sm), tc = block_sum(c, sm + 16);
     if (threadIdx.x == 0) { p_rz[blockIdx.x] = ta; p_bb[blockIdx.x] = tc; }
 }
-__global__ __launch_bounds__(256) void k_pcg_init2(const double *__restrict__ p_rz, const double *__restrict__ p_bb, int cnt, Ctrl *ctrl) {
+__global__ __launch_bounds__(256) void k_pcg_init2(const double *__restrict__ p_rz, int cnt_rz, const double *__restrict__ p_bb, int cnt, Ctrl *ctrl) {
     __shared__ double sm[32];
-    double rz = reduce_partials(p_rz, cnt, sm), bb = reduce_partials(p_bb, cnt, sm + 16);
+    double rz = reduce_partials(p_rz, cnt_rz, sm), bb = reduce_partials(p_bb, cnt, sm + 16);
     if (threadIdx.x == 0) {
         ctrl->val[V_RZ] = rz; ctrl->val[V_BNORM] = sqrt(bb);
         ctrl->cnt[C_PCG_DONE] = (bb == 0.0) ? 1 : 0;
@@ -1011,11 +1034,11 @@ __global__ __launch_bounds__(256) void k_pcg_update(int n, const Ctrl *__restric
     if (threadIdx.x == 0) { p_rz[blockIdx.x] = ta; p_rr[blockIdx.x] = tc; }
 }
 // scalar step: convergence latch, beta, rz roll-over (single block)
-__global__ __launch_bounds__(256) void k_pcg_scalar(Ctrl *ctrl, const double *__restrict__ p_rz, const double *__restrict__ p_rr, int cnt,
-                                                    double tol) {
+__global__ __launch_bounds__(256) void k_pcg_scalar(Ctrl *ctrl, const double *__restrict__ p_rz, int cnt_rz, const double *__restrict__ p_rr,
+                                                    int cnt, double tol) {
     __shared__ double sm[32];
     if (ctrl->cnt[C_PCG_DONE]) return;
-    const double rz2 = reduce_partials(p_rz, cnt, sm), rr = reduce_partials(p_rr, cnt, sm + 16);
+    const double rz2 = reduce_partials(p_rz, cnt_rz, sm), rr = reduce_partials(p_rr, cnt, sm + 16);
     if (threadIdx.x == 0) {
         ctrl->cnt[C_PCG_IT] += 1;
         if (sqrt(rr) <= tol * ctrl->val[V_BNORM] || !(rr == rr)) ctrl->cnt[C_PCG_DONE] = 1;
@@ -1027,6 +1050,110 @@ __global__ void k_pcg_p(int n, const Ctrl *__restrict__ ctrl, const double *__re
     if (ctrl->cnt[C_PCG_DONE]) return;
     const double beta = ctrl->val[V_RR];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = z[i] + beta * p[i];
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Heavy-row deflation of the Jacobi preconditioner.  After a penalty update a handful of rows carry
+// weights d_i 1e4..1e6 times the median; they add isolated huge eigenvalues that cost Jacobi-PCG
+// thousands of iterations.  M = P + A_h' D_h A_h treats the (<= 64) heaviest rows exactly, with P the
+// Jacobi diagonal of the remainder:  M^-1 r = u - P^-1 A_h' S^-1 A_h u,  u = P^-1 r,
+// S = D_h^-1 + A_h P^-1 A_h'  (Woodbury; S is <= 64 x 64 and is inverted on the host once per pass).
+// The solution of K dx = rhs is unchanged; only the iteration count drops.
+// ------------------------------------------------------------------------------------------------
+static const int DEFL_MAX = 64;
+// hist[b] = #{ i : dmax/2^(b+1) < d_i <= dmax/2^b },  b = 0..31
+__global__ __launch_bounds__(256) void k_defl_hist(int m, const double *__restrict__ dw, const Ctrl *ctrl, int *__restrict__ hist) {
+    __shared__ int lh[32];
+    if (threadIdx.x < 32) lh[threadIdx.x] = 0;
+    __syncthreads();
+    const double dmax = __longlong_as_double((long long)ctrl->nrm[N_A]);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const double v = dw[i];
+        if (v > 0.0) {
+            int b = 0; double t = dmax;
+            while (b < 31 && v <= t * 0.5) { t *= 0.5; b++; }
+            atomicAdd(&lh[b], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+// ordered selection of rows with d_i > thr (single block): list, indicator flag, remainder weights
+__global__ __launch_bounds__(1024) void k_defl_select(int m, const double *__restrict__ dw, double thr, double *__restrict__ flag,
+                                                      double *__restrict__ dlight, int *__restrict__ list, int *__restrict__ count) {
+    __shared__ int sums[1024];
+    const int chunk = (m + 1023) / 1024;
+    const int beg = threadIdx.x * chunk, end = min(beg + chunk, m);
+    int c = 0;
+    for (int i = beg; i < end; i++) c += (dw[i] > thr);
+    sums[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; i++) { int t = sums[i]; sums[i] = run; run += t; } *count = run; }
+    __syncthreads();
+    int pos = sums[threadIdx.x];
+    for (int i = beg; i < end; i++) {
+        const bool h = dw[i] > thr;
+        flag[i] = h ? 1.0 : 0.0;
+        dlight[i] = h ? 0.0 : dw[i];
+        if (h) { if (pos < DEFL_MAX) list[pos] = i; pos++; }
+    }
+}
+// S(a,b) = [a==b]/d_a + sum_c A(h_a,c) A(h_b,c) / P_c ; one wave per pair, binary search in the sorted row b
+__global__ __launch_bounds__(64) void k_defl_S(int r, const int *__restrict__ list, const int *__restrict__ arp, const int *__restrict__ aci,
+                                               const double *__restrict__ aval, const double *__restrict__ P, const double *__restrict__ dw,
+                                               double *__restrict__ S) {
+    const int a = blockIdx.x, b = blockIdx.y;
+    if (a >= r || b > a) return;
+    const int ra = list[a], rb = list[b];
+    const int b0 = arp[rb], b1 = arp[rb + 1];
+    double sacc = 0.0;
+    for (int e = arp[ra] + threadIdx.x; e < arp[ra + 1]; e += 64) {
+        const int c = aci[e];
+        int lo = b0, hi = b1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (aci[mid] < c) lo = mid + 1; else hi = mid; }
+        if (lo < b1 && aci[lo] == c) sacc += aval[e] * aval[lo] / P[c];
+    }
+    sacc = wave_sum(sacc);
+    if (threadIdx.x == 0) {
+        if (a == b) sacc += 1.0 / dw[ra];
+        S[a * DEFL_MAX + b] = sacc; S[b * DEFL_MAX + a] = sacc;
+    }
+}
+// v_a = A(h_a,:) u ; one wave per heavy row
+__global__ __launch_bounds__(64) void k_defl_v(const int *__restrict__ done, int r, const int *__restrict__ list, const int *__restrict__ arp,
+                                               const int *__restrict__ aci, const double *__restrict__ aval, const double *__restrict__ u,
+                                               double *__restrict__ v) {
+    if (done && *done) return;
+    const int a = blockIdx.x;
+    if (a >= r) return;
+    const int row = list[a];
+    double sacc = 0.0;
+    for (int e = arp[row] + threadIdx.x; e < arp[row + 1]; e += 64) sacc += aval[e] * u[aci[e]];
+    sacc = wave_sum(sacc);
+    if (threadIdx.x == 0) v[a] = sacc;
+}
+// w = S^-1 v (explicit inverse, row per lane), scattered to the m-vector th at the heavy rows
+__global__ __launch_bounds__(64) void k_defl_w(const int *__restrict__ done, int r, const double *__restrict__ Sinv, const double *__restrict__ v,
+                                               const int *__restrict__ list, double *__restrict__ th) {
+    if (done && *done) return;
+    const int a = threadIdx.x;
+    if (a >= r) return;
+    double sacc = 0.0;
+    for (int b = 0; b < r; b++) sacc += Sinv[a * DEFL_MAX + b] * v[b];
+    th[list[a]] = sacc;
+}
+struct EpiDeflZ {                          // z = u - (A_h' w) ./ P ; partial r.z
+    const double *P, *r; double *z, *p_rz; double acc = 0.0;
+    __device__ bool skip(int) const { return false; }
+    __device__ void row(int j, double s) { const double zj = z[j] - s / P[j]; z[j] = zj; acc += r[j] * zj; }
+    __device__ void finish(double *sm) {
+        double t = block_sum(acc, sm);
+        if (threadIdx.x == 0) p_rz[blockIdx.x] = t;
+    }
+};
+__global__ void k_copy(int n, const double *__restrict__ a, double *__restrict__ b) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) b[i] = a[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1534,6 +1661,26 @@ int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *
             if (!rc) rc = dev_alloc(d, &d->row_cnt, (size_t)n);
         }
         if (!rc) rc = dev_alloc(d, &d->qdiag, (size_t)n);
+        const char *df = getenv("QPDO_DEFLATE");
+        d->deflate = !(df && !strcmp(df, "0"));
+        int mx = 0;
+        for (int i = 0; i < m; i++) { const int len = Ar->rp[i + 1] - Ar->rp[i]; if (len > mx) mx = len; }
+        d->max_row_nnz_A = mx;
+        if (d->deflate && m > 0) {
+            d->Ath = DevCsr(); d->Ath.nrows = n; d->Ath.ncols = m;
+            if (!rc) rc = dev_alloc(d, &d->Ath.rp, (size_t)n + 1);
+            if (!rc) rc = dev_alloc(d, &d->Ath.ci, (size_t)DEFL_MAX * (mx > 0 ? mx : 1));
+            if (!rc) rc = dev_alloc(d, &d->Ath.val, (size_t)DEFL_MAX * (mx > 0 ? mx : 1));
+            if (!rc && !d->row_cnt) rc = dev_alloc(d, &d->row_cnt, (size_t)n);
+            if (!rc) rc = dev_alloc(d, &d->defl_hist, 32);
+            if (!rc) rc = dev_alloc(d, &d->defl_list, DEFL_MAX);
+            if (!rc) rc = dev_alloc(d, &d->defl_count, 1);
+            if (!rc) rc = dev_alloc(d, &d->defl_flag, (size_t)m);
+            if (!rc) rc = dev_alloc(d, &d->defl_t, (size_t)m);
+            if (!rc) rc = dev_alloc(d, &d->defl_S, (size_t)DEFL_MAX * DEFL_MAX);
+            if (!rc) rc = dev_alloc(d, &d->defl_Sinv, (size_t)DEFL_MAX * DEFL_MAX);
+            if (!rc) rc = dev_alloc(d, &d->defl_v, DEFL_MAX);
+        }
     }
     if (rc) { qdev_destroy(d); return rc; }
     d->st.linsolve = 0;
@@ -1775,6 +1922,89 @@ static int compact_At(QpdoDev *d) {
     d->Atc.nnz = nnz2;
     return 0;
 }
+// choose the heavy rows of this pass and build P, At_h, S^-1.  Sets d->defl_r (0 = plain Jacobi).
+static int defl_build(QpdoDev *d, const DevCsr *AtP) {
+    const int n = d->n, m = d->m;
+    d->defl_r = 0;
+    if (!d->deflate || m == 0) return 0;
+    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
+    LAUNCH(k_absmax_mul, vgrid(m), m, (const double *)d->d, (const double *)nullptr, d->ctrl, N_A);
+    HIPCHK(hipMemsetAsync(d->defl_hist, 0, 32 * sizeof(int), d->stream));
+    LAUNCH(k_defl_hist, vgrid(m), m, (const double *)d->d, (const Ctrl *)d->ctrl, d->defl_hist);
+    int hist[32];
+    HIPCHK(hipMemcpyAsync(hist, d->defl_hist, sizeof(hist), hipMemcpyDeviceToHost, d->stream));
+    int rc = read_ctrl(d); if (rc) return rc;
+    const double dmax = nrm_of(d->hctrl, N_A);
+    if (!(dmax > 0.0)) return 0;
+    // largest bucket index k whose cumulative count still fits; rows in buckets 0..k are > dmax / 2^(k+1)
+    int cum = 0, k = -1, total = 0;
+    for (int b = 0; b < 32; b++) total += hist[b];
+    if (total <= 4 * DEFL_MAX) return 0;           // few weighted rows: plain Jacobi-PCG ends within ~n iterations anyway
+    for (int b = 0; b < 32; b++) { if (cum + hist[b] > DEFL_MAX) break; cum += hist[b]; k = b; }
+    if (k < 2 && cum < total) return 0;            // no row is at least 8x heavier than the rest: nothing to deflate
+    if (cum == 0) return 0;
+    const double thr = (cum == total) ? 0.0 : dmax * ldexp(1.0, -(k + 1));
+    hipLaunchKernelGGL(k_defl_select, dim3(1), dim3(1024), 0, d->stream, m, (const double *)d->d, thr, d->defl_flag, d->tmp_m, d->defl_list, d->defl_count);
+    int r = 0;
+    HIPCHK(hipMemcpyAsync(&r, d->defl_count, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (r <= 0 || r > DEFL_MAX) return 0;
+    // P: Jacobi diagonal of the remainder
+    const int gAt = d->At.use_slab ? 2048 : spmv_grid(d->At, d->At.tpr, false);
+    DISPATCH_TPR(d->At, k_jacobi_diag2, gAt, n, AtP->rp, AtP->ci, AtP->val, (const double *)d->tmp_m, (const double *)d->d, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
+    // At_h: columns of the heavy rows
+    DISPATCH_TPR(d->At, k_count_flagged, gAt, n, AtP->rp, AtP->ci, (const double *)d->defl_flag, d->row_cnt);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d->stream, d->row_cnt, n, d->Ath.rp);
+    LAUNCH(k_compact_rows, 2048, n, AtP->rp, AtP->ci, AtP->val, (const double *)d->defl_flag, (const int *)d->Ath.rp, d->Ath.ci, d->Ath.val);
+    d->Ath.tpr = 4; d->Ath.use_slab = 0; d->Ath.nnz = (long long)r * d->max_row_nnz_A;
+    HIPCHK(hipMemsetAsync(d->defl_t, 0, (size_t)m * 8, d->stream));
+    // S and its inverse (host, r <= 64)
+    hipLaunchKernelGGL(k_defl_S, dim3(r, r), dim3(64), 0, d->stream, r, (const int *)d->defl_list, d->Ar.rp, d->Ar.ci, d->Ar.val,
+                       (const double *)d->pc_diag, (const double *)d->d, d->defl_S);
+    static thread_local double S[DEFL_MAX * DEFL_MAX], L[DEFL_MAX * DEFL_MAX], Li[DEFL_MAX * DEFL_MAX], Si[DEFL_MAX * DEFL_MAX];
+    HIPCHK(hipMemcpyAsync(S, d->defl_S, sizeof(S), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    const int N = DEFL_MAX;
+    for (int i = 0; i < r; i++)                     // Cholesky S = L L'
+        for (int j = 0; j <= i; j++) {
+            double t = S[i * N + j];
+            for (int q = 0; q < j; q++) t -= L[i * N + q] * L[j * N + q];
+            if (i == j) { if (!(t > 0.0)) return 0; L[i * N + i] = sqrt(t); }
+            else L[i * N + j] = t / L[j * N + j];
+        }
+    for (int c = 0; c < r; c++)                     // Li = L^-1 (lower)
+        for (int i = 0; i < r; i++) {
+            if (i < c) { Li[i * N + c] = 0.0; continue; }
+            double t = (i == c) ? 1.0 : 0.0;
+            for (int q = c; q < i; q++) t -= L[i * N + q] * Li[q * N + c];
+            Li[i * N + c] = t / L[i * N + i];
+        }
+    memset(Si, 0, sizeof(Si));
+    for (int i = 0; i < r; i++)                     // S^-1 = Li' Li
+        for (int j = 0; j <= i; j++) {
+            double t = 0.0;
+            for (int q = i; q < r; q++) t += Li[q * N + i] * Li[q * N + j];
+            Si[i * N + j] = t; Si[j * N + i] = t;
+        }
+    HIPCHK(hipMemcpyAsync(d->defl_Sinv, Si, sizeof(Si), hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    d->defl_r = r;
+    d->defl_passes++;
+    return 0;
+}
+// z <- M^-1 r given u = P^-1 r in z; leaves the r.z partials in p_rz.  Returns their count.
+static int defl_apply(QpdoDev *d, const int *done, double *p_rz) {
+    const int r = d->defl_r;
+    hipLaunchKernelGGL(k_defl_v, dim3(r), dim3(64), 0, d->stream, done, r, (const int *)d->defl_list, d->Ar.rp, d->Ar.ci, d->Ar.val,
+                       (const double *)d->pc_z, d->defl_v);
+    hipLaunchKernelGGL(k_defl_w, dim3(1), dim3(64), 0, d->stream, done, r, (const double *)d->defl_Sinv, (const double *)d->defl_v,
+                       (const int *)d->defl_list, d->defl_t);
+    EpiDeflZ e{d->pc_diag, d->pc_r, d->pc_z, p_rz};
+    if (done) launch_spmv_pcg(d, d->Ath, d->defl_t, e, true);
+    else launch_spmv(d, d->Ath, d->defl_t, e, true);
+    d->st.spmv_calls--; d->st.spmv_bytes -= (int64_t)d->Ath.alg_bytes();     // not one of the big products
+    return spmv_pgrid(d->Ath);
+}
 static int pcg_solve(QpdoDev *d, int *iters_out) {
     const int n = d->n;
     if (!d->qdiag_valid) {
@@ -1783,13 +2013,22 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
     }
     const DevCsr *AtP = &d->At;
     if (d->compact) { int rc = compact_At(d); if (rc) return rc; AtP = &d->Atc; }
-    // Jacobi diagonal: Q_jj + sigma_f + sum_i A_ij^2 d_i
-    const int gAt = d->At.use_slab ? 2048 : spmv_grid(d->At, d->At.tpr, false);
-    DISPATCH_TPR(d->At, k_jacobi_diag, gAt, n, AtP->rp, AtP->ci, AtP->val, (const double *)d->d, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
+    int rc = defl_build(d, AtP); if (rc) return rc;
+    const bool defl = d->defl_r > 0;
+    if (!defl) {   // Jacobi diagonal: Q_jj + sigma_f + sum_i A_ij^2 d_i
+        const int gAt = d->At.use_slab ? 2048 : spmv_grid(d->At, d->At.tpr, false);
+        DISPATCH_TPR(d->At, k_jacobi_diag, gAt, n, AtP->rp, AtP->ci, AtP->val, (const double *)d->d, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
+    }
     const int g = vgrid(n);
     double *P = d->part;
+    const int *done = &d->ctrl->cnt[C_PCG_DONE];
     LAUNCH(k_pcg_init, g, n, d->rhs, d->pc_diag, d->dx, d->pc_r, d->pc_z, d->pc_p, P + P_RZ * PGRID, P + P_RR * PGRID);
-    LAUNCH(k_pcg_init2, 1, P + P_RZ * PGRID, P + P_RR * PGRID, g, d->ctrl);
+    int cnt_rz = g;
+    if (defl) {
+        cnt_rz = defl_apply(d, nullptr, P + P_RZ * PGRID);
+        LAUNCH(k_copy, g, n, (const double *)d->pc_z, d->pc_p);
+    }
+    LAUNCH(k_pcg_init2, 1, P + P_RZ * PGRID, cnt_rz, P + P_RR * PGRID, g, d->ctrl);
     const int pAt = spmv_pgrid(*AtP);
     int it = 0;
     while (it < d->pcg_maxit) {
@@ -1804,11 +2043,12 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
             launch_spmv_pcg(d, *AtP, d->pc_t, EpiPcgAt{d->pc_p, d->pc_Kp, P + P_PKP * PGRID}, true);
             LAUNCH(k_pcg_update, g, n, d->ctrl, P + P_PKP * PGRID, pAt, d->pc_p, d->pc_Kp, d->pc_diag, d->dx, d->pc_r, d->pc_z,
                    P + P_RZ * PGRID, P + P_RR * PGRID);
-            LAUNCH(k_pcg_scalar, 1, d->ctrl, P + P_RZ * PGRID, P + P_RR * PGRID, g, d->pcg_tol);
+            if (defl) defl_apply(d, done, P + P_RZ * PGRID);
+            LAUNCH(k_pcg_scalar, 1, d->ctrl, P + P_RZ * PGRID, cnt_rz, P + P_RR * PGRID, g, d->pcg_tol);
             LAUNCH(k_pcg_p, g, n, d->ctrl, d->pc_z, d->pc_p);
         }
         it += batch;
-        int rc = read_ctrl(d); if (rc) return rc;
+        rc = read_ctrl(d); if (rc) return rc;
         if (d->hctrl->cnt[C_PCG_IT] > it_before) {      // the sampled (first) iteration of this batch really ran
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, d->ev0, d->ev1) == hipSuccess) { d->ev_spmv_ms += ms; d->ev_spmv_n++; }

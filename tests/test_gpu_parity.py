@@ -4,7 +4,7 @@ identical; iterates within ITERATE_RTOL; KKT residuals within KKT_ATOL."""
 import numpy as np
 import pytest
 
-from helpers import ITERATE_RTOL, KKT_ATOL, close_vec, golden_problem, load_golden
+from helpers import ITERATE_RTOL, ITERATE_RTOL_PCG, KKT_ATOL, close_vec, golden_problem, load_golden
 from oracle import binding as ob
 from qpdo_amd import problems, solver
 
@@ -19,13 +19,17 @@ def linsolve(request, monkeypatch):
     return request.param
 
 
-def assert_same_outcome(res, ref_info, ref_x, ref_y, prob=None):
+def rtol_of(linsolve):
+    return ITERATE_RTOL if linsolve == "dense" else ITERATE_RTOL_PCG
+
+
+def assert_same_outcome(res, ref_info, ref_x, ref_y, prob=None, rtol=ITERATE_RTOL):
     i = res["info"]
     assert i["status_val"] == ref_info["status_val"]
     assert i["iterations"] == ref_info["iterations"]
     assert i["oterations"] == ref_info["oterations"]
-    assert close_vec(res["x"], ref_x), np.abs(np.asarray(res["x"]) - np.asarray(ref_x)).max()
-    assert close_vec(res["y"], ref_y), np.abs(np.asarray(res["y"]) - np.asarray(ref_y)).max()
+    assert close_vec(res["x"], ref_x, rtol), np.abs(np.asarray(res["x"]) - np.asarray(ref_x)).max()
+    assert close_vec(res["y"], ref_y, rtol), np.abs(np.asarray(res["y"]) - np.asarray(ref_y)).max()
     if prob is not None and i["status_val"] == 1:
         rp, rd = problems.kkt_residuals(prob, res["x"], res["y"])
         rp0, rd0 = problems.kkt_residuals(prob, np.asarray(ref_x), np.asarray(ref_y))
@@ -39,7 +43,7 @@ def test_against_golden_vectors(name, linsolve, gpu_required):
     p = golden_problem(g["spec"])
     r = solver.solve_problem(p, verbose=0, **g["settings"])
     assert r["stats"]["linsolve"] == (1 if linsolve == "dense" else 0)
-    assert_same_outcome(r, g, g["x"], g["y"], p)
+    assert_same_outcome(r, g, g["x"], g["y"], p, rtol_of(linsolve))
     assert [t["kind"] for t in r["trace"]] == g["kinds"]
     assert [t["n_active"] for t in r["trace"]] == g["n_active"]
     assert close_vec(r["prim_inf_cert"], g["prim_inf_cert"], 1e-6)
@@ -71,7 +75,7 @@ def test_random_instances_match_live_oracle(seed, n, m, dens, neq, st, linsolve,
     o = ob.OracleSolver(p, ob.default_settings(**st))
     ro = o.solve()
     r = solver.solve_problem(p, verbose=0, **st)
-    assert_same_outcome(r, ro["info"], ro["x"], ro["y"], p)
+    assert_same_outcome(r, ro["info"], ro["x"], ro["y"], p, rtol_of(linsolve))
     to, tg = o.trace(), r["trace"]
     assert [t["kind"] for t in tg] == [t["kind"] for t in to]
     assert [t["n_active"] for t in tg] == [t["n_active"] for t in to]
@@ -140,27 +144,28 @@ def test_warm_start_and_update_sequence_matches_oracle(linsolve, gpu_required):
     p = problems.config_qp("C1")
     o = ob.OracleSolver(p, ob.default_settings())
     s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0)
+    rt = rtol_of(linsolve)
     ro, rg = o.solve(), s.solve()
-    assert_same_outcome(rg, ro["info"], ro["x"], ro["y"], p)
+    assert_same_outcome(rg, ro["info"], ro["x"], ro["y"], p, rt)
     rng = np.random.default_rng(0)
     xw, yw = ro["x"] + 1e-3 * rng.standard_normal(p["n"]), ro["y"] + 1e-3 * rng.standard_normal(p["m"])
     o.warm_start(xw, yw); s.warm_start(xw, yw)
     ro, rg = o.solve(), s.solve()
-    assert_same_outcome(rg, ro["info"], ro["x"], ro["y"], p)
+    assert_same_outcome(rg, ro["info"], ro["x"], ro["y"], p, rt)
     l2, u2 = p["l"] - 0.1, p["u"] + 0.05
     o.update_bounds(l2, u2); s.update_bounds(l2, u2)
     ro, rg = o.solve(), s.solve()
     p2 = dict(p); p2["l"], p2["u"] = l2, u2
-    assert_same_outcome(rg, ro["info"], ro["x"], ro["y"], p2)
+    assert_same_outcome(rg, ro["info"], ro["x"], ro["y"], p2, rt)
     q2 = 1.5 * p["q"] + 0.1
     o.update_q(q2); s.update_q(q2)
     ro, rg = o.solve(), s.solve()
     p3 = dict(p2); p3["q"] = q2
-    assert_same_outcome(rg, ro["info"], ro["x"], ro["y"], p3)
+    assert_same_outcome(rg, ro["info"], ro["x"], ro["y"], p3, rt)
     so = ob.default_settings(eps_abs=1e-8, scaling=15)
     o.update_settings(so); s.update_settings(eps_abs=1e-8, scaling=15)
     ro, rg = o.solve(), s.solve()
-    assert_same_outcome(rg, ro["info"], ro["x"], ro["y"], p3)
+    assert_same_outcome(rg, ro["info"], ro["x"], ro["y"], p3, rt)
     # error contract: decreasing scaling, inconsistent bounds -> QPDO_ERROR (reference src/qpdo.c:487-494,533)
     s.update_settings(scaling=3)
     assert s.info()["status_val"] == -99
