@@ -65,6 +65,7 @@ struct DevCsr {
     // position inside row r where slab s starts (rows are column-sorted, so a slab is a sub-range)
     int use_slab = 0, nslabs = 0, W = 0, rows_per_wg = 0, slab_grid = 0;
     int *sp = nullptr;
+    unsigned short *ci16 = nullptr;   // column index inside its slab (W < 65536): 10 instead of 12 bytes per nonzero
     double alg_bytes() const { return 12.0 * (double)nnz + 4.0 * (nrows + 1) + 8.0 * nrows + 8.0 * ncols; }
 };
 
@@ -72,8 +73,10 @@ struct QpdoDev {
     int device = 0, n = 0, m = 0;
     hipStream_t stream = nullptr;
     DevCsr Ar, At, Qf;
-    DevCsr Atc;               // A' compacted to the weighted columns of the current Newton pass
-    int *row_cnt = nullptr; int compact = 1;
+    // compact index space of the current Newton pass: the k weighted rows of A, renumbered 0..k-1
+    DevCsr Arc, Atc;          // A_c (k x n) and A_c' (n x k)
+    int *row_cnt = nullptr, *cidx = nullptr, *rowlist = nullptr, *kcount = nullptr; int kact = 0;
+    double *dc = nullptr, *tc = nullptr; int lds_doubles_At = 0;
     double *qdiag = nullptr; int qdiag_valid = 0;
     // heavy-row deflation
     int deflate = 1, defl_r = 0, max_row_nnz_A = 0; DevCsr Ath; int *defl_hist = nullptr, *defl_list = nullptr, *defl_count = nullptr;
@@ -234,9 +237,10 @@ __global__ __launch_bounds__(256) void k_spmv(int nrows, const int *__restrict__
 // ------------------------------------------------------------------------------------------------
 static const int SLAB_THREADS = 1024;
 static const int SLAB_TPR = 16;
-template <class Epi>
+template <class Epi, bool I16>
 __global__ __launch_bounds__(1024) void k_spmv_slab(const int *__restrict__ done, int nrows, int ncols, int nslabs, int W,
                                                     int rows_per_wg, const int *__restrict__ sp, const int *__restrict__ ci,
+                                                    const unsigned short *__restrict__ ci16,
                                                     const double *__restrict__ val, const double *__restrict__ x, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sm[32];
@@ -271,11 +275,11 @@ __global__ __launch_bounds__(1024) void k_spmv_slab(const int *__restrict__ done
             int k = beg + lane;
             for (; k + SLAB_TPR < end; k += 2 * SLAB_TPR) {
                 const double v0 = val[k], v1 = val[k + SLAB_TPR];
-                const int a0 = ci[k] - c0, a1 = ci[k + SLAB_TPR] - c0;
+                const int a0 = I16 ? (int)ci16[k] : ci[k] - c0, a1 = I16 ? (int)ci16[k + SLAB_TPR] : ci[k + SLAB_TPR] - c0;
                 s0 += v0 * xs[a0];
                 s1 += v1 * xs[a1];
             }
-            if (k < end) s0 += val[k] * xs[ci[k] - c0];
+            if (k < end) s0 += val[k] * xs[I16 ? (int)ci16[k] : ci[k] - c0];
             double t = s0 + s1;
 #pragma unroll
             for (int o = SLAB_TPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, SLAB_TPR);
@@ -379,9 +383,9 @@ struct EpiAdxLs {
         }
     }
 };
-struct EpiPcgA {                           // t = d .* (A p); rows with zero weight are not read
+struct EpiPcgA {                           // t = d_c .* (A_c p) in the compact row space of the pass
     const double *d; double *t; const int *done;
-    __device__ bool skip(int r) const { return d[r] == 0.0; }
+    __device__ bool skip(int) const { return false; }
     __device__ void row(int r, double s) { t[r] = d[r] * s; }
     __device__ void finish(double *) {}
 };
@@ -390,6 +394,15 @@ struct EpiPcgQ {                           // Kp = Q p + sigma_f p
     __device__ bool skip(int) const { return false; }
     __device__ void row(int r, double s) { Kp[r] = s + sigma_f * p[r]; }
     __device__ void finish(double *) {}
+};
+struct EpiPcgQdot {                        // no weighted rows: Kp = Q p + sigma_f p and the p.Kp partials in one go
+    const double *p; double sigma_f; double *Kp, *p_pKp; double acc = 0.0;
+    __device__ bool skip(int) const { return false; }
+    __device__ void row(int r, double s) { const double v = s + sigma_f * p[r]; Kp[r] = v; acc += p[r] * v; }
+    __device__ void finish(double *sm) {
+        double t = block_sum(acc, sm);
+        if (threadIdx.x == 0) p_pKp[blockIdx.x] = t;
+    }
 };
 struct EpiPcgAt {                          // Kp += A' t ; partial p.Kp
     const double *p; double *Kp, *p_pKp; double acc = 0.0;
@@ -415,11 +428,16 @@ static void launch_spmv_slab(QpdoDev *d, const DevCsr &M, const double *x, Epi e
     const size_t lds = ((size_t)M.W + (size_t)M.rows_per_wg) * sizeof(double);
     static thread_local bool attr_set = false;   // per instantiation
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab<Epi, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab<Epi, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_spmv_slab<Epi>), dim3(M.slab_grid), dim3(SLAB_THREADS), lds, d->stream, done, M.nrows, M.ncols, M.nslabs, M.W,
-                       M.rows_per_wg, M.sp, M.ci, M.val, x, epi);
+    if (M.ci16)
+        hipLaunchKernelGGL((k_spmv_slab<Epi, true>), dim3(M.slab_grid), dim3(SLAB_THREADS), lds, d->stream, done, M.nrows, M.ncols, M.nslabs, M.W,
+                           M.rows_per_wg, M.sp, M.ci, M.ci16, M.val, x, epi);
+    else
+        hipLaunchKernelGGL((k_spmv_slab<Epi, false>), dim3(M.slab_grid), dim3(SLAB_THREADS), lds, d->stream, done, M.nrows, M.ncols, M.nslabs, M.W,
+                           M.rows_per_wg, M.sp, M.ci, M.ci16, M.val, x, epi);
     d->st.spmv_calls++;
     d->st.spmv_bytes += (int64_t)M.alg_bytes();
 }
@@ -582,6 +600,49 @@ __global__ void k_extract_diag(int n, const int *__restrict__ rp, const int *__r
     }
 }
 
+// compact index space of a Newton pass: cidx[i] = number of weighted rows before i, rowlist = their ids (single block)
+__global__ __launch_bounds__(1024) void k_flag_scan(int m, const double *__restrict__ dw, int *__restrict__ cidx, int *__restrict__ rowlist,
+                                                    int *__restrict__ count) {
+    __shared__ int sums[1024];
+    const int chunk = (m + 1023) / 1024;
+    const int beg = threadIdx.x * chunk, end = min(beg + chunk, m);
+    int c = 0;
+    for (int i = beg; i < end; i++) c += (dw[i] != 0.0);
+    sums[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; i++) { int t = sums[i]; sums[i] = run; run += t; } *count = run; }
+    __syncthreads();
+    int pos = sums[threadIdx.x];
+    for (int i = beg; i < end; i++) { cidx[i] = pos; if (dw[i] != 0.0) { rowlist[pos] = i; pos++; } }
+}
+__global__ void k_gather_rowinfo(int k, const int *__restrict__ rowlist, const int *__restrict__ rp, const double *__restrict__ dw,
+                                 int *__restrict__ cnt, double *__restrict__ dc) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x) {
+        const int r = rowlist[j];
+        cnt[j] = rp[r + 1] - rp[r]; dc[j] = dw[r];
+    }
+}
+// copy the listed rows of a CSR matrix into a contiguous CSR (one wave per row)
+__global__ __launch_bounds__(256) void k_copy_rows(int k, const int *__restrict__ rowlist, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                   const unsigned short *__restrict__ ci16, const double *__restrict__ val,
+                                                   const int *__restrict__ rp2, int *__restrict__ ci2, unsigned short *__restrict__ ci16_2,
+                                                   double *__restrict__ val2) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * BLK + threadIdx.x) >> 6;
+    const int nwaves = gridDim.x * (BLK >> 6);
+    for (int j = wave; j < k; j += nwaves) {
+        const int r = rowlist[j];
+        const int src = rp[r], len = rp[r + 1] - src, dst = rp2[j];
+        for (int e = lane; e < len; e += 64) {
+            ci2[dst + e] = ci[src + e]; val2[dst + e] = val[src + e];
+            if (ci16) ci16_2[dst + e] = ci16[src + e];
+        }
+    }
+}
+__global__ void k_fill_ci16(long long nnz, const int *__restrict__ ci, int W, unsigned short *__restrict__ ci16) {
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x)
+        ci16[k] = (unsigned short)(ci[k] % W);
+}
 // ---- per-pass compaction of CSR(A') to the columns (constraints) that carry weight ------------------
 // Rows of A with d_i == 0 contribute exact zeros to A' (d .* (A p)); dropping those entries from the
 // n x m CSR once per Newton pass removes their HBM traffic from every PCG iteration.  Order inside a
@@ -614,10 +675,13 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int *__restrict__ cn
     int run = sums[threadIdx.x];
     for (int i = beg; i < end; i++) { out[i] = run; run += cnt[i]; }
 }
-// one wave per row: stable compaction of (ci, val) pairs whose column weight is nonzero
+// one wave per row: stable compaction of (ci, val) pairs whose column weight is nonzero; kept columns are
+// renumbered through `remap` (monotone, so rows stay column-sorted) and, if W16 > 0, their slab-local
+// 16-bit index is produced as well
 __global__ __launch_bounds__(256) void k_compact_rows(int nrows, const int *__restrict__ rp, const int *__restrict__ ci,
                                                       const double *__restrict__ val, const double *__restrict__ dw,
-                                                      const int *__restrict__ rp2, int *__restrict__ ci2, double *__restrict__ val2) {
+                                                      const int *__restrict__ rp2, int *__restrict__ ci2, double *__restrict__ val2,
+                                                      const int *__restrict__ remap, int W16, unsigned short *__restrict__ ci16) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * BLK + threadIdx.x) >> 6;
     const int nwaves = gridDim.x * (BLK >> 6);
@@ -629,7 +693,12 @@ __global__ __launch_bounds__(256) void k_compact_rows(int nrows, const int *__re
             int c = 0; double v = 0.0; bool keep = false;
             if (k < end) { c = ci[k]; v = val[k]; keep = dw[c] != 0.0; }
             const u64 bal = __ballot(keep);
-            if (keep) { const int pos = base + __popcll(bal & ((1ull << lane) - 1ull)); ci2[pos] = c; val2[pos] = v; }
+            if (keep) {
+                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                const int cn = remap ? remap[c] : c;
+                ci2[pos] = cn; val2[pos] = v;
+                if (W16 > 0) ci16[pos] = (unsigned short)(cn % W16);
+            }
             base += __popcll(bal);
         }
     }
@@ -754,6 +823,9 @@ __global__ void k_sub(int n, const double *__restrict__ a, const double *__restr
 }
 __global__ void k_axpy(int n, double sc, const double *__restrict__ b, double *__restrict__ a) {   // a = a + sc b
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = a[i] + sc * b[i];
+}
+__global__ void k_axpy_const(int n, const double *__restrict__ a, double c, double *__restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = a[i] + c;
 }
 __global__ void k_mul(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ c) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c[i] = a[i] * b[i];
@@ -1591,6 +1663,12 @@ static int setup_slabs(QpdoDev *d, DevCsr *M) {
     hipLaunchKernelGGL(k_build_slab_ptr, dim3(vgrid(M->nrows)), dim3(BLK), 0, d->stream, M->nrows, M->rp, M->ci, nslabs, W, M->sp, &d->ctrl->cnt[C_VIOL]);
     rc = read_ctrl(d); if (rc) return rc;
     M->use_slab = d->hctrl->cnt[C_VIOL] ? 0 : 1;          // unsorted rows: keep the plain kernel
+    const char *i16 = getenv("QPDO_IDX16");
+    if (M->use_slab && W < 65536 && !(i16 && !strcmp(i16, "0"))) {
+        rc = dev_alloc(d, &M->ci16, (size_t)M->nnz);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_fill_ci16, dim3(2048), dim3(BLK), 0, d->stream, M->nnz, M->ci, W, M->ci16);
+    }
     return 0;
 }
 static int read_ctrl(QpdoDev *d) {
@@ -1649,17 +1727,26 @@ int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *
     if (!rc) rc = setup_slabs(d, &d->Ar);
     if (!rc) rc = setup_slabs(d, &d->At);
     if (!rc) rc = setup_slabs(d, &d->Qf);
-    if (!rc) {   // compacted copy of A' shares the slab geometry of A'
-        const char *cm = getenv("QPDO_COMPACT");
-        d->compact = !(cm && !strcmp(cm, "0"));
-        d->Atc = d->At; d->Atc.rp = nullptr; d->Atc.ci = nullptr; d->Atc.val = nullptr; d->Atc.sp = nullptr;
-        if (d->compact) {
-            rc = dev_alloc(d, &d->Atc.rp, (size_t)n + 1);
-            if (!rc) rc = dev_alloc(d, &d->Atc.ci, (size_t)At->nnz);
-            if (!rc) rc = dev_alloc(d, &d->Atc.val, (size_t)At->nnz);
-            if (!rc && d->At.use_slab) rc = dev_alloc(d, &d->Atc.sp, (size_t)n * (d->At.nslabs + 1));
-            if (!rc) rc = dev_alloc(d, &d->row_cnt, (size_t)n);
-        }
+    if (!rc) {   // per-pass compact copies used by PCG
+        d->Arc = d->Ar; d->Arc.rp = nullptr; d->Arc.ci = nullptr; d->Arc.val = nullptr; d->Arc.sp = nullptr; d->Arc.ci16 = nullptr;
+        d->Atc = d->At; d->Atc.rp = nullptr; d->Atc.ci = nullptr; d->Atc.val = nullptr; d->Atc.sp = nullptr; d->Atc.ci16 = nullptr;
+        rc = dev_alloc(d, &d->Arc.rp, (size_t)m + 1);
+        if (!rc) rc = dev_alloc(d, &d->Arc.ci, (size_t)Ar->nnz);
+        if (!rc) rc = dev_alloc(d, &d->Arc.val, (size_t)Ar->nnz);
+        if (!rc && d->Ar.use_slab) rc = dev_alloc(d, &d->Arc.sp, (size_t)m * (d->Ar.nslabs + 1));
+        if (!rc && d->Ar.ci16) rc = dev_alloc(d, &d->Arc.ci16, (size_t)Ar->nnz);
+        if (!rc) rc = dev_alloc(d, &d->Atc.rp, (size_t)n + 1);
+        if (!rc) rc = dev_alloc(d, &d->Atc.ci, (size_t)At->nnz);
+        if (!rc) rc = dev_alloc(d, &d->Atc.val, (size_t)At->nnz);
+        if (!rc && d->At.use_slab) rc = dev_alloc(d, &d->Atc.sp, (size_t)n * (d->At.nslabs + 1));
+        if (!rc && d->At.ci16) rc = dev_alloc(d, &d->Atc.ci16, (size_t)At->nnz);
+        if (!rc) rc = dev_alloc(d, &d->row_cnt, (size_t)(n > m ? n : m));
+        if (!rc) rc = dev_alloc(d, &d->cidx, (size_t)m);
+        if (!rc) rc = dev_alloc(d, &d->rowlist, (size_t)m);
+        if (!rc) rc = dev_alloc(d, &d->kcount, 4);
+        if (!rc) rc = dev_alloc(d, &d->dc, (size_t)m);
+        if (!rc) rc = dev_alloc(d, &d->tc, (size_t)m);
+        d->lds_doubles_At = (160 * 1024 - 1024) / 8 - d->At.rows_per_wg;
         if (!rc) rc = dev_alloc(d, &d->qdiag, (size_t)n);
         const char *df = getenv("QPDO_DEFLATE");
         d->deflate = !(df && !strcmp(df, "0"));
@@ -1671,7 +1758,6 @@ int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *
             if (!rc) rc = dev_alloc(d, &d->Ath.rp, (size_t)n + 1);
             if (!rc) rc = dev_alloc(d, &d->Ath.ci, (size_t)DEFL_MAX * (mx > 0 ? mx : 1));
             if (!rc) rc = dev_alloc(d, &d->Ath.val, (size_t)DEFL_MAX * (mx > 0 ? mx : 1));
-            if (!rc && !d->row_cnt) rc = dev_alloc(d, &d->row_cnt, (size_t)n);
             if (!rc) rc = dev_alloc(d, &d->defl_hist, 32);
             if (!rc) rc = dev_alloc(d, &d->defl_list, DEFL_MAX);
             if (!rc) rc = dev_alloc(d, &d->defl_count, 1);
@@ -1906,61 +1992,96 @@ int qdev_residuals(QpdoDev *d, int proximal, double sigma, QdevResid *out) {
 }
 
 // ---- linear solve -----------------------------------------------------------------------------------
-// build Atc for the current weights d (once per Newton pass)
-static int compact_At(QpdoDev *d) {
-    const int n = d->n;
-    const DevCsr &M = d->At;
-    const int g = spmv_grid(M, M.tpr, false) > 4096 ? 4096 : (M.use_slab ? 2048 : spmv_grid(M, M.tpr, false));
-    DISPATCH_TPR(M, k_count_flagged, g, n, M.rp, M.ci, (const double *)d->d, d->row_cnt);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d->stream, d->row_cnt, n, d->Atc.rp);
-    LAUNCH(k_compact_rows, 2048, n, M.rp, M.ci, M.val, (const double *)d->d, (const int *)d->Atc.rp, d->Atc.ci, d->Atc.val);
-    if (M.use_slab)
-        LAUNCH(k_build_slab_ptr, vgrid(n), n, d->Atc.rp, d->Atc.ci, M.nslabs, M.W, d->Atc.sp, &d->ctrl->cnt[C_VIOL]);
-    int nnz2 = 0;
-    HIPCHK(hipMemcpyAsync(&nnz2, d->Atc.rp + n, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+// Build the compact index space of this Newton pass: k weighted rows, A_c (k x n) copied out of CSR(A),
+// A_c' (n x k) compacted out of CSR(A') with renumbered columns, d_c.  ~4 passes over A, once per Newton pass.
+static int build_compact(QpdoDev *d) {
+    const int n = d->n, m = d->m;
+    d->kact = 0;
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(k_flag_scan, dim3(1), dim3(1024), 0, d->stream, m, (const double *)d->d, d->cidx, d->rowlist, d->kcount);
+    int k = 0;
+    HIPCHK(hipMemcpyAsync(&k, d->kcount, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
-    d->Atc.nnz = nnz2;
+    if (k <= 0) return 0;
+    // A_c: rows
+    LAUNCH(k_gather_rowinfo, vgrid(k), k, (const int *)d->rowlist, d->Ar.rp, (const double *)d->d, d->row_cnt, d->dc);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d->stream, d->row_cnt, k, d->Arc.rp);
+    LAUNCH(k_copy_rows, 2048, k, (const int *)d->rowlist, d->Ar.rp, d->Ar.ci, (const unsigned short *)d->Ar.ci16, d->Ar.val,
+           (const int *)d->Arc.rp, d->Arc.ci, d->Arc.ci16, d->Arc.val);
+    DevCsr &R = d->Arc;
+    R.nrows = k; R.ncols = n; R.tpr = d->Ar.tpr; R.use_slab = d->Ar.use_slab && k >= 4096;
+    if (R.use_slab) {
+        R.nslabs = d->Ar.nslabs; R.W = d->Ar.W;
+        R.rows_per_wg = (k + 255) / 256; R.slab_grid = (k + R.rows_per_wg - 1) / R.rows_per_wg;
+        LAUNCH(k_build_slab_ptr, vgrid(k), k, R.rp, R.ci, R.nslabs, R.W, R.sp, &d->kcount[1]);
+    }
+    // A_c': columns, renumbered
+    DevCsr &T = d->Atc;
+    const DevCsr &M = d->At;
+    T.nrows = n; T.ncols = k; T.tpr = M.tpr; T.use_slab = M.use_slab && k >= 1024;
+    int W16 = 0;
+    if (T.use_slab) {
+        T.rows_per_wg = M.rows_per_wg; T.slab_grid = M.slab_grid;
+        int nslabs = (k + d->lds_doubles_At - 1) / d->lds_doubles_At; if (nslabs < 1) nslabs = 1;
+        int W = ((k + nslabs - 1) / nslabs + 63) & ~63;
+        if (W > d->lds_doubles_At) { nslabs++; W = ((k + nslabs - 1) / nslabs + 63) & ~63; }
+        if (nslabs > M.nslabs) { nslabs = M.nslabs; W = M.W; }           // never more slabs than the sp table holds
+        T.nslabs = nslabs; T.W = W;
+        if (T.ci16 && W < 65536) W16 = W;
+    }
+    const int g = M.use_slab ? 2048 : spmv_grid(M, M.tpr, false);
+    DISPATCH_TPR(M, k_count_flagged, g, n, M.rp, M.ci, (const double *)d->d, d->row_cnt);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d->stream, d->row_cnt, n, T.rp);
+    LAUNCH(k_compact_rows, 2048, n, M.rp, M.ci, M.val, (const double *)d->d, (const int *)T.rp, T.ci, T.val, (const int *)d->cidx, W16,
+           M.ci16 ? d->Atc.ci16 : (unsigned short *)nullptr);
+    DevCsr Tsave = T;     // (keep pointer to allocated ci16 even when this pass cannot use it)
+    if (T.use_slab) LAUNCH(k_build_slab_ptr, vgrid(n), n, T.rp, T.ci, T.nslabs, T.W, T.sp, &d->kcount[1]);
+    int nn[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&nn[0], d->Arc.rp + k, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipMemcpyAsync(&nn[1], T.rp + n, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    R.nnz = nn[0]; T.nnz = nn[1];
+    (void)Tsave;
+    d->kact = k;
     return 0;
 }
-// choose the heavy rows of this pass and build P, At_h, S^-1.  Sets d->defl_r (0 = plain Jacobi).
-static int defl_build(QpdoDev *d, const DevCsr *AtP) {
-    const int n = d->n, m = d->m;
+// choose the heavy rows of this pass (in the compact space) and build P, A_h', S^-1.  Sets d->defl_r.
+static int defl_build(QpdoDev *d) {
+    const int n = d->n, k = d->kact;
     d->defl_r = 0;
-    if (!d->deflate || m == 0) return 0;
+    if (!d->deflate || k <= 4 * DEFL_MAX) return 0;   // few weighted rows: plain Jacobi-PCG ends within ~n iterations anyway
     LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
-    LAUNCH(k_absmax_mul, vgrid(m), m, (const double *)d->d, (const double *)nullptr, d->ctrl, N_A);
+    LAUNCH(k_absmax_mul, vgrid(k), k, (const double *)d->dc, (const double *)nullptr, d->ctrl, N_A);
     HIPCHK(hipMemsetAsync(d->defl_hist, 0, 32 * sizeof(int), d->stream));
-    LAUNCH(k_defl_hist, vgrid(m), m, (const double *)d->d, (const Ctrl *)d->ctrl, d->defl_hist);
+    LAUNCH(k_defl_hist, vgrid(k), k, (const double *)d->dc, (const Ctrl *)d->ctrl, d->defl_hist);
     int hist[32];
     HIPCHK(hipMemcpyAsync(hist, d->defl_hist, sizeof(hist), hipMemcpyDeviceToHost, d->stream));
     int rc = read_ctrl(d); if (rc) return rc;
     const double dmax = nrm_of(d->hctrl, N_A);
     if (!(dmax > 0.0)) return 0;
-    // largest bucket index k whose cumulative count still fits; rows in buckets 0..k are > dmax / 2^(k+1)
-    int cum = 0, k = -1, total = 0;
-    for (int b = 0; b < 32; b++) total += hist[b];
-    if (total <= 4 * DEFL_MAX) return 0;           // few weighted rows: plain Jacobi-PCG ends within ~n iterations anyway
-    for (int b = 0; b < 32; b++) { if (cum + hist[b] > DEFL_MAX) break; cum += hist[b]; k = b; }
-    if (k < 2 && cum < total) return 0;            // no row is at least 8x heavier than the rest: nothing to deflate
-    if (cum == 0) return 0;
-    const double thr = (cum == total) ? 0.0 : dmax * ldexp(1.0, -(k + 1));
-    hipLaunchKernelGGL(k_defl_select, dim3(1), dim3(1024), 0, d->stream, m, (const double *)d->d, thr, d->defl_flag, d->tmp_m, d->defl_list, d->defl_count);
+    // largest bucket index kb whose cumulative count still fits; rows in buckets 0..kb are > dmax / 2^(kb+1)
+    int cum = 0, kb = -1;
+    for (int b = 0; b < 32; b++) { if (cum + hist[b] > DEFL_MAX) break; cum += hist[b]; kb = b; }
+    if (kb < 2 || cum == 0) return 0;              // no group of <= 64 rows stands out by a factor of 8: nothing to deflate
+    const double thr = dmax * ldexp(1.0, -(kb + 1));
+    hipLaunchKernelGGL(k_defl_select, dim3(1), dim3(1024), 0, d->stream, k, (const double *)d->dc, thr, d->defl_flag, d->tmp_m, d->defl_list, d->defl_count);
     int r = 0;
     HIPCHK(hipMemcpyAsync(&r, d->defl_count, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     if (r <= 0 || r > DEFL_MAX) return 0;
-    // P: Jacobi diagonal of the remainder
+    const DevCsr &T = d->Atc;
+    // P: Jacobi diagonal of the remainder (floored), A_h': the heavy columns of A_c'
     const int gAt = d->At.use_slab ? 2048 : spmv_grid(d->At, d->At.tpr, false);
-    DISPATCH_TPR(d->At, k_jacobi_diag2, gAt, n, AtP->rp, AtP->ci, AtP->val, (const double *)d->tmp_m, (const double *)d->d, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
-    // At_h: columns of the heavy rows
-    DISPATCH_TPR(d->At, k_count_flagged, gAt, n, AtP->rp, AtP->ci, (const double *)d->defl_flag, d->row_cnt);
+    DISPATCH_TPR(d->At, k_jacobi_diag2, gAt, n, T.rp, T.ci, T.val, (const double *)d->tmp_m, (const double *)d->dc, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
+    DISPATCH_TPR(d->At, k_count_flagged, gAt, n, T.rp, T.ci, (const double *)d->defl_flag, d->row_cnt);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d->stream, d->row_cnt, n, d->Ath.rp);
-    LAUNCH(k_compact_rows, 2048, n, AtP->rp, AtP->ci, AtP->val, (const double *)d->defl_flag, (const int *)d->Ath.rp, d->Ath.ci, d->Ath.val);
-    d->Ath.tpr = 4; d->Ath.use_slab = 0; d->Ath.nnz = (long long)r * d->max_row_nnz_A;
-    HIPCHK(hipMemsetAsync(d->defl_t, 0, (size_t)m * 8, d->stream));
+    LAUNCH(k_compact_rows, 2048, n, T.rp, T.ci, T.val, (const double *)d->defl_flag, (const int *)d->Ath.rp, d->Ath.ci, d->Ath.val,
+           (const int *)nullptr, 0, (unsigned short *)nullptr);
+    d->Ath.nrows = n; d->Ath.ncols = k; d->Ath.tpr = 4; d->Ath.use_slab = 0; d->Ath.nnz = (long long)r * d->max_row_nnz_A;
+    HIPCHK(hipMemsetAsync(d->defl_t, 0, (size_t)k * 8, d->stream));
     // S and its inverse (host, r <= 64)
-    hipLaunchKernelGGL(k_defl_S, dim3(r, r), dim3(64), 0, d->stream, r, (const int *)d->defl_list, d->Ar.rp, d->Ar.ci, d->Ar.val,
-                       (const double *)d->pc_diag, (const double *)d->d, d->defl_S);
+    hipLaunchKernelGGL(k_defl_S, dim3(r, r), dim3(64), 0, d->stream, r, (const int *)d->defl_list, d->Arc.rp, d->Arc.ci, d->Arc.val,
+                       (const double *)d->pc_diag, (const double *)d->dc, d->defl_S);
     static thread_local double S[DEFL_MAX * DEFL_MAX], L[DEFL_MAX * DEFL_MAX], Li[DEFL_MAX * DEFL_MAX], Si[DEFL_MAX * DEFL_MAX];
     HIPCHK(hipMemcpyAsync(S, d->defl_S, sizeof(S), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
@@ -1995,7 +2116,7 @@ static int defl_build(QpdoDev *d, const DevCsr *AtP) {
 // z <- M^-1 r given u = P^-1 r in z; leaves the r.z partials in p_rz.  Returns their count.
 static int defl_apply(QpdoDev *d, const int *done, double *p_rz) {
     const int r = d->defl_r;
-    hipLaunchKernelGGL(k_defl_v, dim3(r), dim3(64), 0, d->stream, done, r, (const int *)d->defl_list, d->Ar.rp, d->Ar.ci, d->Ar.val,
+    hipLaunchKernelGGL(k_defl_v, dim3(r), dim3(64), 0, d->stream, done, r, (const int *)d->defl_list, d->Arc.rp, d->Arc.ci, d->Arc.val,
                        (const double *)d->pc_z, d->defl_v);
     hipLaunchKernelGGL(k_defl_w, dim3(1), dim3(64), 0, d->stream, done, r, (const double *)d->defl_Sinv, (const double *)d->defl_v,
                        (const int *)d->defl_list, d->defl_t);
@@ -2011,13 +2132,17 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
         LAUNCH(k_extract_diag, vgrid(n), n, d->Qf.rp, d->Qf.ci, d->Qf.val, d->qdiag);
         d->qdiag_valid = 1;
     }
-    const DevCsr *AtP = &d->At;
-    if (d->compact) { int rc = compact_At(d); if (rc) return rc; AtP = &d->Atc; }
-    int rc = defl_build(d, AtP); if (rc) return rc;
+    int rc = build_compact(d); if (rc) return rc;
+    const int k = d->kact;
+    rc = defl_build(d); if (rc) return rc;
     const bool defl = d->defl_r > 0;
     if (!defl) {   // Jacobi diagonal: Q_jj + sigma_f + sum_i A_ij^2 d_i
-        const int gAt = d->At.use_slab ? 2048 : spmv_grid(d->At, d->At.tpr, false);
-        DISPATCH_TPR(d->At, k_jacobi_diag, gAt, n, AtP->rp, AtP->ci, AtP->val, (const double *)d->d, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
+        if (k > 0) {
+            const int gAt = d->At.use_slab ? 2048 : spmv_grid(d->At, d->At.tpr, false);
+            DISPATCH_TPR(d->At, k_jacobi_diag, gAt, n, d->Atc.rp, d->Atc.ci, d->Atc.val, (const double *)d->dc, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
+        } else {
+            LAUNCH(k_axpy_const, vgrid(n), n, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
+        }
     }
     const int g = vgrid(n);
     double *P = d->part;
@@ -2029,19 +2154,25 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
         LAUNCH(k_copy, g, n, (const double *)d->pc_z, d->pc_p);
     }
     LAUNCH(k_pcg_init2, 1, P + P_RZ * PGRID, cnt_rz, P + P_RR * PGRID, g, d->ctrl);
-    const int pAt = spmv_pgrid(*AtP);
+    const int pKp_cnt = k > 0 ? spmv_pgrid(d->Atc) : spmv_pgrid(d->Qf);
     int it = 0;
     while (it < d->pcg_maxit) {
         const int it_before = it;
         int batch = d->pcg_batch; if (it + batch > d->pcg_maxit) batch = d->pcg_maxit - it;
         for (int b = 0; b < batch; b++) {
-            launch_spmv_pcg(d, d->Ar, d->pc_p, EpiPcgA{d->d, d->pc_t, nullptr}, false);
             const bool sample = (b == 0);
-            if (sample) hipEventRecord(d->ev0, d->stream);
-            launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQ{d->pc_p, d->sigma_f, d->pc_Kp}, false);
-            if (sample) hipEventRecord(d->ev1, d->stream);
-            launch_spmv_pcg(d, *AtP, d->pc_t, EpiPcgAt{d->pc_p, d->pc_Kp, P + P_PKP * PGRID}, true);
-            LAUNCH(k_pcg_update, g, n, d->ctrl, P + P_PKP * PGRID, pAt, d->pc_p, d->pc_Kp, d->pc_diag, d->dx, d->pc_r, d->pc_z,
+            if (k > 0) {
+                launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
+                if (sample) hipEventRecord(d->ev0, d->stream);
+                launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQ{d->pc_p, d->sigma_f, d->pc_Kp}, false);
+                if (sample) hipEventRecord(d->ev1, d->stream);
+                launch_spmv_pcg(d, d->Atc, d->tc, EpiPcgAt{d->pc_p, d->pc_Kp, P + P_PKP * PGRID}, true);
+            } else {
+                if (sample) hipEventRecord(d->ev0, d->stream);
+                launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQdot{d->pc_p, d->sigma_f, d->pc_Kp, P + P_PKP * PGRID}, true);
+                if (sample) hipEventRecord(d->ev1, d->stream);
+            }
+            LAUNCH(k_pcg_update, g, n, d->ctrl, P + P_PKP * PGRID, pKp_cnt, d->pc_p, d->pc_Kp, d->pc_diag, d->dx, d->pc_r, d->pc_z,
                    P + P_RZ * PGRID, P + P_RR * PGRID);
             if (defl) defl_apply(d, done, P + P_RZ * PGRID);
             LAUNCH(k_pcg_scalar, 1, d->ctrl, P + P_RZ * PGRID, cnt_rz, P + P_RR * PGRID, g, d->pcg_tol);
