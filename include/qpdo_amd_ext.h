@@ -7,7 +7,10 @@
  *
  * Environment variables read once per qpdo_setup:
  *   QPDO_DEVICE      HIP device ordinal (default: LOCAL_RANK if set, else 0)
- *   QPDO_LINSOLVE    "pcg" | "dense" | "auto" (default auto: dense for n <= QPDO_DENSE_MAX_N)
+ *   QPDO_LINSOLVE    "pcg" | "dense" | "auto" (default auto: dense LDL' for n <= QPDO_DENSE_MAX_N = 8192)
+ *   QPDO_SPMV        "slab" | "plain" (default: LDS-staged slab kernel for matrices >= 192 MB)
+ *   QPDO_DEFLATE     "0" disables the heavy-row deflation of the PCG preconditioner
+ *   QPDO_IDX16       "0" disables the 16-bit slab-local column indices
  *   QPDO_PCG_TOL     relative residual tolerance of the Jacobi-PCG solve (default 1e-12)
  *   QPDO_PCG_MAXIT   PCG iteration cap per Newton step (default 100000)
  *   QPDO_FIX_STATUS_RESET  "1": reset info->status_val at the start of qpdo_solve
@@ -63,6 +66,20 @@ int  qpdo_amd_linesearch(QPDOWorkspace *work, double eta, double beta, const dou
 /* copy a device-resident vector to the host: 0 x, 1 Qx, 2 y, 3 mu, 4 d (factor weights),
  * 5 dx, 6 dy, 7 Ax, 8 Aty, 9 l, 10 u */
 int  qpdo_amd_download(QPDOWorkspace *work, int which, double *dst);
+
+/* ---- batch of independent QPs (BASELINE.json configs[2]: MPC-sized problems, no collective) --------------
+ * Every item is set up, (optionally warm started,) solved and cleaned up through the same entry points as above,
+ * by `nthreads` host threads, each with its own workspace and HIP stream on the device of this process
+ * (QPDO_DEVICE); across GPUs the caller shards the item list over processes.  x (n) and y (m) receive the
+ * solution (NaN for infeasible statuses, as the reference's mex gateway does), info the final QPDOInfo. */
+typedef struct {
+    const QPDOData *data;       /* problem (caller-owned, read only)                     */
+    const c_float  *x0, *y0;    /* optional warm start (NULL: cold)                      */
+    c_float        *x, *y;      /* out: solution, caller-allocated, length n / m         */
+    QPDOInfo        info;       /* out                                                    */
+} QPDOAmdBatchItem;
+/* returns the number of items whose setup failed (their info.status_val is QPDO_ERROR) */
+long qpdo_amd_solve_batch(long count, QPDOAmdBatchItem *items, const QPDOSettings *settings, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <pthread.h>
 
 #include "qpdo.h"
 #include "qpdo_amd_ext.h"
@@ -703,4 +704,46 @@ int qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out) {
     out->spmv_Q_avg_s = avg;
     out->spmv_Q_samples = ns;
     return 0;
+}
+
+/* ---- batch of independent QPs ------------------------------------------------------------------------------ */
+typedef struct { long count; QPDOAmdBatchItem *items; const QPDOSettings *settings; long next; long failed; pthread_mutex_t mu; } BatchCtx;
+static void *batch_worker(void *arg) {
+    BatchCtx *b = (BatchCtx *)arg;
+    for (;;) {
+        pthread_mutex_lock(&b->mu);
+        long i = b->next++;
+        pthread_mutex_unlock(&b->mu);
+        if (i >= b->count) break;
+        QPDOAmdBatchItem *it = &b->items[i];
+        const size_t n = it->data->n, m = it->data->m;
+        QPDOWorkspace *w = qpdo_setup(it->data, b->settings);
+        if (!w) {
+            memset(&it->info, 0, sizeof(it->info));
+            update_status(&it->info, QPDO_ERROR);
+            pthread_mutex_lock(&b->mu); b->failed++; pthread_mutex_unlock(&b->mu);
+            continue;
+        }
+        if (it->x0 || it->y0) qpdo_warm_start(w, (c_float *)it->x0, (c_float *)it->y0);
+        qpdo_solve(w);
+        it->info = *w->info;
+        const int infeasible = (w->info->status_val == QPDO_PRIMAL_INFEASIBLE) || (w->info->status_val == QPDO_DUAL_INFEASIBLE);
+        if (it->x) for (size_t k = 0; k < n; k++) it->x[k] = infeasible ? NAN : w->solution->x[k];
+        if (it->y) for (size_t k = 0; k < m; k++) it->y[k] = infeasible ? NAN : w->solution->y[k];
+        qpdo_cleanup(w);
+    }
+    return NULL;
+}
+long qpdo_amd_solve_batch(long count, QPDOAmdBatchItem *items, const QPDOSettings *settings, int nthreads) {
+    if (count <= 0) return 0;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    if (nthreads > count) nthreads = (int)count;
+    BatchCtx b = {count, items, settings, 0, 0, PTHREAD_MUTEX_INITIALIZER};
+    pthread_t th[64];
+    int started = 0;
+    for (int t = 0; t < nthreads; t++) if (pthread_create(&th[started], NULL, batch_worker, &b) == 0) started++;
+    if (started == 0) batch_worker(&b);
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    return b.failed;
 }

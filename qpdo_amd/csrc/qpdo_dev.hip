@@ -82,8 +82,8 @@ struct QpdoDev {
     int deflate = 1, defl_r = 0, max_row_nnz_A = 0; DevCsr Ath; int *defl_hist = nullptr, *defl_list = nullptr, *defl_count = nullptr;
     double *defl_flag = nullptr, *defl_t = nullptr, *defl_S = nullptr, *defl_Sinv = nullptr, *defl_v = nullptr; long long defl_passes = 0;
     // dense direct solver
-    int dense_ld = 0, dense_nblk = 0, dense_max_n = 16384; int dense_valid = 0;
-    double *Kd = nullptr, *Wd = nullptr, *Dg = nullptr, *dz = nullptr, *dxw = nullptr;
+    int dense_ld = 0, dense_nblk = 0, dense_max_n = 8192;   // measured crossover with deflated PCG: n ~ 8e3 int dense_valid = 0;
+    double *Kd = nullptr, *Wd = nullptr, *Dg = nullptr, *Linv = nullptr, *dz = nullptr, *dxw = nullptr;
     int dense_last_branch = -1; double dense_last_sigma = -1.0;
     // n-vectors
     double *x, *xbar, *Qx, *Aty, *q, *df, *res_dual, *res_dual_in, *rhs, *dx, *Qdx, *Atdy, *D, *Dinv;
@@ -1453,72 +1453,87 @@ __global__ __launch_bounds__(64) void k_dense_assemble(int n, int ld, const int 
         for (int i = j + lane; i < ld; i += 64) col[i] = (i < n) ? acc[i] : 0.0;
     }
 }
-// LDL' of the 64x64 diagonal block kb in LDS; writes unit-lower L back and D to Dg
-__global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ K, int ld, int kb, double *__restrict__ Dg) {
-    __shared__ double a[DNB][DNB + 1];
-    __shared__ double colv[DNB];
-    const int tid = threadIdx.x;
-    const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
-    for (int idx = tid; idx < DNB * DNB; idx += 256) { const int r = idx % DNB, c = idx / DNB; a[r][c] = K[base + r + (size_t)c * ld]; }
-    __syncthreads();
-    for (int j = 0; j < DNB; j++) {
-        const double dj = a[j][j];
-        if (tid > j && tid < DNB) colv[tid] = a[tid][j];           // v_i = l_ij d_j
-        __syncthreads();
-        // trailing update of the lower triangle: a_ic -= v_i v_c / d_j  for j < c <= i
-        const int t = DNB - 1 - j;
-        for (int idx = tid; idx < t * t; idx += 256) {
-            const int i = j + 1 + idx / t, c = j + 1 + idx % t;
-            if (c <= i) a[i][c] -= colv[i] * (colv[c] / dj);
-        }
-        if (tid > j && tid < DNB) a[tid][j] = colv[tid] / dj;
-        __syncthreads();
-    }
-    for (int idx = tid; idx < DNB * DNB; idx += 256) {
-        const int r = idx % DNB, c = idx / DNB;
-        if (r > c) K[base + r + (size_t)c * ld] = a[r][c];
-    }
-    if (tid < DNB) Dg[kb * DNB + tid] = a[tid][tid];
-}
-// panel below the diagonal block: X L_kk' = A  =>  W = X (= L D), L = X / D.  One thread per row.
-__global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ K, int ld, int kb, const double *__restrict__ Dg,
-                                                   double *__restrict__ W) {
-    __shared__ double L[DNB][DNB + 1];
-    __shared__ double dinv[DNB];
-    const int tid = threadIdx.x;
-    const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
-    for (int idx = tid; idx < DNB * DNB; idx += 256) { const int r = idx % DNB, c = idx / DNB; L[r][c] = (r > c) ? K[base + r + (size_t)c * ld] : 0.0; }
-    if (tid < DNB) dinv[tid] = 1.0 / Dg[kb * DNB + tid];
-    __syncthreads();
-    const int r = (kb + 1) * DNB + blockIdx.x * 256 + tid;
-    if (r >= ld) return;
-    double x[DNB];
-    double *row = K + r + (size_t)kb * DNB * ld;
-#pragma unroll
-    for (int c = 0; c < DNB; c++) x[c] = row[(size_t)c * ld];
-#pragma unroll
-    for (int c = 0; c < DNB; c++) {
-        double sacc = x[c];
-#pragma unroll
-        for (int cp = 0; cp < c; cp++) sacc -= x[cp] * L[c][cp];
-        x[c] = sacc;
-    }
-#pragma unroll
-    for (int c = 0; c < DNB; c++) { W[r + (size_t)c * ld] = x[c]; row[(size_t)c * ld] = x[c] * dinv[c]; }
-}
-// trailing update on the matrix cores: C(ti,tj) -= W(ti) * L(tj)'  for kb < tj <= ti.
-// 4 waves, each a 32x32 quadrant as 2x2 tiles of v_mfma_f64_16x16x4_f64.
+// 64x64x64 product on the matrix cores for one workgroup of 4 waves: wave w owns the 32x32 quadrant
+// (w>>1, w&1) as 2x2 tiles of v_mfma_f64_16x16x4_f64; As/Bs are [k][row] / [k][col] LDS images with a row
+// stride of 80 doubles (the two k-rows a half-wave reads land on disjoint banks).
 // A/B lane map: lane l holds A[l&15][k = l>>4], B[k = l>>4][l&15]; C/D: row = (l>>4) + 4*reg, col = l&15.
-__global__ __launch_bounds__(256) void k_ldl_syrk(double *__restrict__ K, int ld, int kb, const double *__restrict__ W) {
-    const int ti = kb + 1 + blockIdx.x, tj = kb + 1 + blockIdx.y;
-    if (tj > ti) return;
-    __shared__ double As[DNB][80];      // [k][row]; row stride 80 doubles keeps the two k-rows of a half-wave on disjoint banks
+__device__ __forceinline__ void mfma_64x64x64(const double (*As)[80], const double (*Bs)[80], dvec4 acc[2][2], int wr, int wc, int li, int lk) {
+#pragma unroll 4
+    for (int k0 = 0; k0 < DNB; k0 += 4) {
+        const double a0 = As[k0 + lk][wr + li], a1 = As[k0 + lk][wr + 16 + li];
+        const double b0 = Bs[k0 + lk][wc + li], b1 = Bs[k0 + lk][wc + 16 + li];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+// LDL' of the 64x64 diagonal block kb; writes unit-lower L back, D to Dg and the inverse of L
+// (column-major: Li[c*64 + r] = (L^-1)[r][c]) for the panel solve and the triangular solves.
+// Register-resident: thread (wave w, lane c) owns column c, rows w, w+4, ..., w+60 of the block (a) and of the
+// running inverse (x, Gauss-Jordan: the row operations of step j applied to the identity).  Per elimination
+// step the owners publish pivot column j+1 and inverse row j+1 through double-buffered LDS: one barrier a step.
+__global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ K, int ld, int kb, double *__restrict__ Dg, double *__restrict__ Linv) {
+    __shared__ double colv[2][DNB];
+    __shared__ double xrow[2][DNB];
+    const int tid = threadIdx.x;
+    const int c = tid & 63, w = tid >> 6;
+    const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
+    double a[16], x[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) { a[rr] = K[base + (w + 4 * rr) + (size_t)c * ld]; x[rr] = (w + 4 * rr == c) ? 1.0 : 0.0; }
+    if (c == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) colv[0][w + 4 * rr] = a[rr];
+    }
+    if (w == 0) xrow[0][c] = x[0];                                 // row 0 of the identity
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < DNB; j++) {
+        const double *cv = colv[j & 1];
+        const double dj = cv[j], inv_dj = 1.0 / dj, xj = xrow[j & 1][c];
+        if (c > j) {                                               // a_ic -= v_i v_c / d_j  for j < c <= i
+            const double wc = cv[c] * inv_dj;
+#pragma unroll
+            for (int rr = 0; rr < 16; rr++) { const int i = w + 4 * rr; if (i >= c) a[rr] -= cv[i] * wc; }
+        } else if (c == j) {                                       // column j becomes L(:,j) = v * (1/d_j), diagonal keeps d_j
+#pragma unroll
+            for (int rr = 0; rr < 16; rr++) { const int i = w + 4 * rr; if (i > j) a[rr] = a[rr] * inv_dj; }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) { const int i = w + 4 * rr; if (i > j) x[rr] -= (cv[i] * inv_dj) * xj; }   // X(i,:) -= l_ij X(j,:)
+        if (c == j + 1) {                                          // publish the next pivot column (already updated)
+#pragma unroll
+            for (int rr = 0; rr < 16; rr++) colv[(j + 1) & 1][w + 4 * rr] = a[rr];
+        }
+        if (w == ((j + 1) & 3)) {                                  // and row j+1 of the running inverse (final after this step)
+#pragma unroll
+            for (int rr = 0; rr < 16; rr++) if (w + 4 * rr == j + 1) xrow[(j + 1) & 1][c] = x[rr];
+        }
+        __syncthreads();
+    }
+    double *o = Linv + (size_t)kb * DNB * DNB;
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) {
+        const int i = w + 4 * rr;
+        if (i > c) K[base + i + (size_t)c * ld] = a[rr];
+        if (i == c) Dg[kb * DNB + c] = a[rr];
+        o[(size_t)c * DNB + i] = x[rr];
+    }
+}
+// panel below the diagonal block on the matrix cores: X = A L_kk^-T  =>  W = X (= L D), L = X / D.
+// One workgroup per 64-row tile.
+__global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ K, int ld, int kb, int wcol, const double *__restrict__ Dg,
+                                                   const double *__restrict__ Linv, double *__restrict__ W) {
+    __shared__ double As[DNB][80];
     __shared__ double Bs[DNB][80];
     const int tid = threadIdx.x;
+    const int ti = kb + 1 + blockIdx.x;
+    const double *Li = Linv + (size_t)kb * DNB * DNB;
     for (int idx = tid; idx < DNB * DNB; idx += 256) {
         const int r = idx % DNB, k = idx / DNB;
-        As[k][r] = W[(size_t)ti * DNB + r + (size_t)k * ld];
-        Bs[k][r] = K[(size_t)tj * DNB + r + ((size_t)kb * DNB + k) * ld];
+        As[k][r] = K[(size_t)ti * DNB + r + ((size_t)kb * DNB + k) * ld];      // A[row r][k]
+        Bs[k][r] = Li[(size_t)k * DNB + r];                                     // B[k][col r] = (L^-1)[r][k]
     }
     __syncthreads();
     const int wave = tid >> 6, l = tid & 63;
@@ -1529,14 +1544,46 @@ __global__ __launch_bounds__(256) void k_ldl_syrk(double *__restrict__ K, int ld
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int q = 0; q < 2; q++) acc[m][q] = (dvec4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int k0 = 0; k0 < DNB; k0 += 4) {
-        const double a0 = As[k0 + lk][wr + li], a1 = As[k0 + lk][wr + 16 + li];
-        const double b0 = Bs[k0 + lk][wc + li], b1 = Bs[k0 + lk][wc + 16 + li];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    mfma_64x64x64(As, Bs, acc, wr, wc, li, lk);
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int row = wr + m * 16 + lk + 4 * v, col = wc + q * 16 + li;
+                const double x = acc[m][q][v];
+                W[(size_t)ti * DNB + row + ((size_t)wcol * DNB + col) * ld] = x;
+                K[(size_t)ti * DNB + row + ((size_t)kb * DNB + col) * ld] = x / Dg[kb * DNB + col];
+            }
+}
+// update on the matrix cores: C(ti,tj) -= sum_{q<nkb} W(ti, wcol0+q) * L(tj, kb0+q)'  for tj in [tj_lo, tj_hi), ti >= tj.
+// nkb = 1 updates the rest of the current 256-wide outer panel, nkb = 4 the trailing matrix (one read-modify-write
+// of C per 256 eliminated columns instead of per 64).
+__global__ __launch_bounds__(256) void k_ldl_syrk(double *__restrict__ K, int ld, const double *__restrict__ W, int kb0, int nkb, int wcol0,
+                                                  int tj_lo, int tj_hi) {
+    const int ti = tj_lo + blockIdx.x, tj = tj_lo + blockIdx.y;
+    if (tj >= tj_hi || tj > ti) return;
+    __shared__ double As[DNB][80];
+    __shared__ double Bs[DNB][80];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, l = tid & 63;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const int li = l & 15, lk = l >> 4;
+    dvec4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) acc[m][q] = (dvec4){0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < nkb; q++) {
+        __syncthreads();
+        for (int idx = tid; idx < DNB * DNB; idx += 256) {
+            const int r = idx % DNB, k = idx / DNB;
+            As[k][r] = W[(size_t)ti * DNB + r + ((size_t)(wcol0 + q) * DNB + k) * ld];
+            Bs[k][r] = K[(size_t)tj * DNB + r + ((size_t)(kb0 + q) * DNB + k) * ld];
+        }
+        __syncthreads();
+        mfma_64x64x64(As, Bs, acc, wr, wc, li, lk);
     }
 #pragma unroll
     for (int m = 0; m < 2; m++)
@@ -1545,21 +1592,21 @@ __global__ __launch_bounds__(256) void k_ldl_syrk(double *__restrict__ K, int ld
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const int row = wr + m * 16 + lk + 4 * v, col = wc + q * 16 + li;
-                double *c = K + (size_t)ti * DNB + row + ((size_t)tj * DNB + col) * ld;
-                *c = *c - acc[m][q][v];
+                double *cp = K + (size_t)ti * DNB + row + ((size_t)tj * DNB + col) * ld;
+                *cp = *cp - acc[m][q][v];
             }
 }
-// forward step kb: every wave re-solves the unit-lower diagonal block for z_k (cheap), wave 0 publishes it,
-// then wave b updates the 64 rows of block kb+1+b:  x_i -= L(i, kb) z_k.
-__global__ __launch_bounds__(64) void k_ldl_fwd(const double *__restrict__ K, int ld, int kb, double *__restrict__ x, double *__restrict__ z) {
-    __shared__ double zs[DNB];
+// forward step kb: z_k = L_kk^-1 x_k (matrix-vector with the stored inverse: no serial chain), wave 0 publishes
+// it, then wave b updates the 64 rows of block kb+1+b:  x_i -= L(i, kb) z_k.
+__global__ __launch_bounds__(64) void k_ldl_fwd(const double *__restrict__ K, int ld, int kb, const double *__restrict__ Linv,
+                                                double *__restrict__ x, double *__restrict__ z) {
+    __shared__ double xs[DNB], zs[DNB];
     const int l = threadIdx.x;
-    const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
-    double v = x[kb * DNB + l];
-    for (int c = 0; c < DNB - 1; c++) {
-        const double zc = __shfl(v, c, 64);
-        if (l > c) v -= K[base + l + (size_t)c * ld] * zc;
-    }
+    xs[l] = x[kb * DNB + l];
+    __syncthreads();
+    const double *Li = Linv + (size_t)kb * DNB * DNB;
+    double v = 0.0;
+    for (int c = 0; c < DNB; c++) v += Li[(size_t)c * DNB + l] * xs[c];
     zs[l] = v;
     if (blockIdx.x == 0) z[kb * DNB + l] = v;
     __syncthreads();
@@ -1570,24 +1617,24 @@ __global__ __launch_bounds__(64) void k_ldl_fwd(const double *__restrict__ K, in
     for (int c = 0; c < DNB; c++) sacc -= row[(size_t)c * ld] * zs[c];
     x[r] = sacc;
 }
-// backward step kb: solve L_kk' x_k = y_k (y = z ./ D already folded in by the caller), publish x_k,
-// then wave j (< kb) updates y_j -= L(kb, j)' x_k through an LDS transpose of the 64x64 tile.
-__global__ __launch_bounds__(64) void k_ldl_bwd(const double *__restrict__ K, int ld, int kb, double *__restrict__ y, double *__restrict__ xout) {
-    __shared__ double xs[DNB];
+// backward step kb: x_k = L_kk^-T y_k, publish, then wave j (< kb) updates y_j -= L(kb, j)' x_k through an LDS
+// transpose of the 64x64 tile.
+__global__ __launch_bounds__(64) void k_ldl_bwd(const double *__restrict__ K, int ld, int kb, const double *__restrict__ Linv,
+                                                double *__restrict__ y, double *__restrict__ xout) {
+    __shared__ double xs[DNB], ys[DNB];
     __shared__ double tile[DNB][DNB + 1];
     const int l = threadIdx.x;
-    const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
-    double v = y[kb * DNB + l];
-    for (int c = DNB - 1; c > 0; c--) {                 // x_c final; rows l < c subtract L[c][l] x_c
-        const double xc = __shfl(v, c, 64);
-        if (l < c) v -= K[base + c + (size_t)l * ld] * xc;
-    }
+    ys[l] = y[kb * DNB + l];
+    const double *Li = Linv + (size_t)kb * DNB * DNB;
+    for (int c = 0; c < DNB; c++) tile[l][c] = Li[(size_t)c * DNB + l];        // tile[r][c] = (L^-1)[r][c]
+    __syncthreads();
+    double v = 0.0;
+    for (int r = 0; r < DNB; r++) v += tile[r][l] * ys[r];                      // (L^-T y)_l = sum_r (L^-1)[r][l] y_r
     xs[l] = v;
     if (blockIdx.x == 0) xout[kb * DNB + l] = v;
     __syncthreads();
-    if (kb == 0) return;
     const int j = blockIdx.x;                            // 0 .. kb-1
-    if (j >= kb) return;
+    if (kb == 0 || j >= kb) return;
     for (int c = 0; c < DNB; c++) tile[l][c] = K[(size_t)kb * DNB + l + ((size_t)j * DNB + c) * ld];   // rows contiguous across lanes
     __syncthreads();
     double sacc = y[j * DNB + l];
@@ -2191,13 +2238,15 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
 }
 
 // ---- dense direct solve ------------------------------------------------------------------------------
+static const int DOUTER = 4;          // inner 64-blocks per outer panel (256 columns)
 static int dense_alloc(QpdoDev *d) {
     if (d->Kd) return 0;
     const int ld = (d->n + DNB - 1) / DNB * DNB;
     d->dense_ld = ld; d->dense_nblk = ld / DNB;
     int rc = dev_alloc(d, &d->Kd, (size_t)ld * ld);
-    if (!rc) rc = dev_alloc(d, &d->Wd, (size_t)ld * DNB);
+    if (!rc) rc = dev_alloc(d, &d->Wd, (size_t)ld * DNB * DOUTER);
     if (!rc) rc = dev_alloc(d, &d->Dg, (size_t)ld);
+    if (!rc) rc = dev_alloc(d, &d->Linv, (size_t)d->dense_nblk * DNB * DNB);
     if (!rc) rc = dev_alloc(d, &d->dz, (size_t)ld);
     if (!rc) rc = dev_alloc(d, &d->dxw, (size_t)ld);
     if (!rc) {
@@ -2212,13 +2261,22 @@ static int dense_factor(QpdoDev *d) {
     const int g = ld < 1024 ? ld : 1024;
     hipLaunchKernelGGL(k_dense_assemble, dim3(g), dim3(64), (size_t)n * sizeof(double), d->stream, n, ld, d->Qf.rp, d->Qf.ci, d->Qf.val,
                        d->At.rp, d->At.ci, d->At.val, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)d->d, d->sigma_f, d->Kd);
-    for (int kb = 0; kb < nb; kb++) {
-        hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), 0, d->stream, d->Kd, ld, kb, d->Dg);
-        const int below = nb - kb - 1;
-        if (below > 0) {
-            hipLaunchKernelGGL(k_ldl_panel, dim3((below * DNB + 255) / 256), dim3(256), 0, d->stream, d->Kd, ld, kb, (const double *)d->Dg, d->Wd);
-            hipLaunchKernelGGL(k_ldl_syrk, dim3(below, below), dim3(256), 0, d->stream, d->Kd, ld, kb, (const double *)d->Wd);
+    for (int J0 = 0; J0 < nb; J0 += DOUTER) {
+        const int Jend = J0 + DOUTER < nb ? J0 + DOUTER : nb;
+        for (int kb = J0; kb < Jend; kb++) {
+            hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), 0, d->stream, d->Kd, ld, kb, d->Dg, d->Linv);
+            const int below = nb - kb - 1;
+            if (below > 0) {
+                hipLaunchKernelGGL(k_ldl_panel, dim3(below), dim3(256), 0, d->stream, d->Kd, ld, kb, kb - J0, (const double *)d->Dg,
+                                   (const double *)d->Linv, d->Wd);
+                if (kb + 1 < Jend)      // rest of this outer panel
+                    hipLaunchKernelGGL(k_ldl_syrk, dim3(nb - (kb + 1), Jend - (kb + 1)), dim3(256), 0, d->stream, d->Kd, ld, (const double *)d->Wd,
+                                       kb, 1, kb - J0, kb + 1, Jend);
+            }
         }
+        if (Jend < nb)                  // trailing matrix: all columns of the outer panel at once
+            hipLaunchKernelGGL(k_ldl_syrk, dim3(nb - Jend, nb - Jend), dim3(256), 0, d->stream, d->Kd, ld, (const double *)d->Wd, J0, Jend - J0, 0,
+                               Jend, nb);
     }
     HIPCHK(hipGetLastError());
     d->dense_valid = 1;
@@ -2230,11 +2288,11 @@ static int dense_solve(QpdoDev *d) {
     LAUNCH(k_dense_load_rhs, vgrid(ld), n, ld, (const double *)d->rhs, d->dxw);
     for (int kb = 0; kb < nb; kb++) {
         const int below = nb - kb - 1;
-        hipLaunchKernelGGL(k_ldl_fwd, dim3(below > 0 ? below : 1), dim3(64), 0, d->stream, (const double *)d->Kd, ld, kb, d->dxw, d->dz);
+        hipLaunchKernelGGL(k_ldl_fwd, dim3(below > 0 ? below : 1), dim3(64), 0, d->stream, (const double *)d->Kd, ld, kb, (const double *)d->Linv, d->dxw, d->dz);
     }
     LAUNCH(k_dense_scale_d, vgrid(ld), ld, (const double *)d->dz, (const double *)d->Dg, d->dz);
     for (int kb = nb - 1; kb >= 0; kb--)
-        hipLaunchKernelGGL(k_ldl_bwd, dim3(kb > 0 ? kb : 1), dim3(64), 0, d->stream, (const double *)d->Kd, ld, kb, d->dz, d->dxw);
+        hipLaunchKernelGGL(k_ldl_bwd, dim3(kb > 0 ? kb : 1), dim3(64), 0, d->stream, (const double *)d->Kd, ld, kb, (const double *)d->Linv, d->dz, d->dxw);
     HIPCHK(hipMemcpyAsync(d->dx, d->dxw, (size_t)n * 8, hipMemcpyDeviceToDevice, d->stream));
     return 0;
 }

@@ -93,7 +93,11 @@ class Stats(C.Structure):
 
 API_SYMBOLS = ["qpdo_set_default_settings", "qpdo_setup", "qpdo_warm_start", "qpdo_solve", "qpdo_update_settings",
                "qpdo_update_bounds", "qpdo_update_q", "qpdo_cleanup"]
-EXT_SYMBOLS = ["qpdo_amd_device_count", "qpdo_amd_last_error", "qpdo_amd_get_stats", "qpdo_amd_get_trace",
+class BatchItem(C.Structure):
+    _fields_ = [("data", C.POINTER(QPDOData)), ("x0", dp), ("y0", dp), ("x", dp), ("y", dp), ("info", QPDOInfo)]
+
+
+EXT_SYMBOLS = ["qpdo_amd_solve_batch", "qpdo_amd_device_count", "qpdo_amd_last_error", "qpdo_amd_get_stats", "qpdo_amd_get_trace",
                "qpdo_amd_sync", "qpdo_amd_bench_spmv", "qpdo_amd_spmv", "qpdo_amd_linesearch", "qpdo_amd_download"]
 
 _lib = None
@@ -123,6 +127,8 @@ def lib():
         L.qpdo_amd_spmv.argtypes = [W, C.c_int, dp, dp]
         L.qpdo_amd_linesearch.argtypes = [W, C.c_double, C.c_double, dp, dp, dp]
         L.qpdo_amd_download.argtypes = [W, C.c_int, dp]
+        L.qpdo_amd_solve_batch.restype = C.c_long
+        L.qpdo_amd_solve_batch.argtypes = [C.c_long, C.POINTER(BatchItem), C.POINTER(QPDOSettings), C.c_int]
         _lib = L
     return _lib
 
@@ -334,3 +340,35 @@ def solve_problem(prob, settings=None, **kw):
     res["stats"], res["trace"] = s.stats(), s.trace()
     s.delete()
     return res
+
+
+def solve_batch(probs, settings=None, nthreads=16, **kw):
+    """Solve independent QPs (dicts from qpdo_amd.problems) concurrently on this process's GPU.
+    Returns a list of dicts (info, x, y)."""
+    if settings is None:
+        settings = default_settings(**kw)
+    keep, items = [], (BatchItem * len(probs))()
+    outs = []
+    for i, p in enumerate(probs):
+        A, Q = sp.csc_matrix(p["A"]), sp.csc_matrix(p["Q"])
+        m, n = A.shape
+        q = np.ascontiguousarray(p["q"], np.float64)
+        l = np.clip(np.ascontiguousarray(p["l"], np.float64), -QPDO_INFTY, QPDO_INFTY)
+        u = np.clip(np.ascontiguousarray(p["u"], np.float64), -QPDO_INFTY, QPDO_INFTY)
+        Qs, As = _sparse_view(Q, p.get("Qstype", -1), keep), _sparse_view(A, 0, keep)
+        data = QPDOData()
+        data.n, data.m, data.Q, data.A = n, m, C.pointer(Qs), C.pointer(As)
+        data.q, data.c, data.l, data.u = _as_dp(q), float(p.get("c", 0.0)), _as_dp(l), _as_dp(u)
+        x, y = np.zeros(n), np.zeros(m)
+        keep.extend([q, l, u, Qs, As, data, x, y])
+        items[i].data = C.pointer(data)
+        items[i].x0, items[i].y0 = None, None
+        items[i].x, items[i].y = _as_dp(x), _as_dp(y)
+        outs.append((x, y))
+    failed = lib().qpdo_amd_solve_batch(len(probs), items, C.byref(settings), int(nthreads))
+    res = []
+    for i, (x, y) in enumerate(outs):
+        info = {f: getattr(items[i].info, f) for f, _ in QPDOInfo._fields_}
+        info["status"] = info["status"].decode()
+        res.append(dict(info=info, x=x, y=y))
+    return res, int(failed)

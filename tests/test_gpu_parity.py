@@ -213,3 +213,18 @@ def test_config2_full_size_properties(gpu_required):
     Ax = p["A"] @ r["x"]
     inside = (Ax > p["l"] + 1e-5) & (Ax < p["u"] - 1e-5)
     assert np.abs(r["y"][inside]).max() <= 1e-5
+
+
+def test_batch_of_mpc_sized_qps_matches_oracle(gpu_required):
+    """BASELINE.json configs[2] (n=120, m=360 with equality rows), a slice of the batch: every item must match
+    the oracle exactly in status / iterations / oterations, and concurrent workspaces must not interfere."""
+    probs = [problems.config_qp("C3", i) for i in range(24)]
+    res, failed = solver.solve_batch(probs, nthreads=8, verbose=0)
+    assert failed == 0
+    for p, r in zip(probs, res):
+        o = ob.OracleSolver(p, ob.default_settings())
+        ro = o.solve()
+        assert (r["info"]["status_val"], r["info"]["iterations"], r["info"]["oterations"]) == \
+               (ro["info"]["status_val"], ro["info"]["iterations"], ro["info"]["oterations"])
+        assert close_vec(r["x"], ro["x"]) and close_vec(r["y"], ro["y"])
+        o.close()
