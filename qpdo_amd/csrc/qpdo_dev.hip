@@ -82,7 +82,8 @@ struct QpdoDev {
     int deflate = 1, defl_r = 0, max_row_nnz_A = 0; DevCsr Ath; int *defl_hist = nullptr, *defl_list = nullptr, *defl_count = nullptr;
     double *defl_flag = nullptr, *defl_t = nullptr, *defl_S = nullptr, *defl_Sinv = nullptr, *defl_v = nullptr; long long defl_passes = 0;
     // dense direct solver
-    int dense_ld = 0, dense_nblk = 0, dense_max_n = 8192;   // measured crossover with deflated PCG: n ~ 8e3 int dense_valid = 0;
+    int dense_ld = 0, dense_nblk = 0, dense_valid = 0;
+    int dense_max_n = 8192;   // measured crossover with deflated PCG: n ~ 8e3
     double *Kd = nullptr, *Wd = nullptr, *Dg = nullptr, *Linv = nullptr, *dz = nullptr, *dxw = nullptr;
     int dense_last_branch = -1; double dense_last_sigma = -1.0;
     // n-vectors
