@@ -565,10 +565,9 @@ static void ldl_solve(Oracle *o, const f64 *b, f64 *x) {
         for (i64 i = j + 1; i < n; i++) x[i] -= cj[i] * xj;
     }
     for (i64 j = 0; j < n; j++) x[j] /= K[j + j*n];
-    for (i64 j = n - 1; j >= 0; j--) {          /* L' x = z */
-        const f64 *cj = K + j*n; f64 s = x[j];
-        for (i64 i = j + 1; i < n; i++) s -= cj[i] * x[i];
-        x[j] = s;
+    for (i64 j = n - 1; j >= 0; j--) {          /* L' x = z, column oriented: x_j is final, eliminate it above */
+        f64 xj = x[j];
+        for (i64 i = 0; i < j; i++) x[i] -= K[j + i*n] * xj;
     }
 }
 

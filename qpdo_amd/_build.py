@@ -13,7 +13,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libqpdo_amd.so")
 GEN_PATH = os.path.join(_HERE, "libqpdo_gen.so")
 
-HIP_SOURCES = ["qpdo_dev.hip"]
+HIP_SOURCES = ["qpdo_dev.hip", "qpdo_small.hip"]
 C_SOURCES = ["qpdo_api.c"]
 HEADERS = ["qpdo_dev.h", os.path.join(INCLUDE, "qpdo.h"), os.path.join(INCLUDE, "qpdo_amd_ext.h")]
 

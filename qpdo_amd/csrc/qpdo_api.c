@@ -736,6 +736,21 @@ static void *batch_worker(void *arg) {
 }
 long qpdo_amd_solve_batch(long count, QPDOAmdBatchItem *items, const QPDOSettings *settings, int nthreads) {
     if (count <= 0) return 0;
+    /* small problems: the fused one-workgroup-per-QP kernel solves the whole batch in one launch
+     * (QPDO_BATCH=threads forces the generic multi-kernel path on a host thread pool) */
+    const char *mode = getenv("QPDO_BATCH");
+    if (!(mode && !strcmp(mode, "threads")) && validate_settings(settings) && qdev_small_eligible(count, items)) {
+        long bad = 0;
+        for (long i = 0; i < count; i++) if (!validate_data(items[i].data)) bad++;
+        if (!bad) {
+            int ndev = qdev_device_count();
+            if (ndev > 0) {
+                int device = env_int("QPDO_DEVICE", env_int("LOCAL_RANK", 0)) % ndev;
+                if (qdev_small_batch(device, count, items, settings) == 0) return 0;
+                QPDO_EPRINT("fused batch kernel failed (%s); using the generic path", qdev_small_last_error());
+            }
+        }
+    }
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 64) nthreads = 64;
     if (nthreads > count) nthreads = (int)count;

@@ -120,6 +120,12 @@ int qdev_spmv(QpdoDev *d, int which, const double *v_host, double *y_host);
 int qdev_linesearch(QpdoDev *d, double eta, double beta, const double *delta, const double *alpha,
                     double *tau);
 
+/* fused one-workgroup-per-QP solver for batches of small problems (qpdo_small.hip) */
+struct QPDOAmdBatchItem_;
+int qdev_small_eligible(long count, const void *items);
+int qdev_small_batch(int device, long count, void *items, const void *settings);
+const char *qdev_small_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

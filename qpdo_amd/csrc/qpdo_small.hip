@@ -1,0 +1,748 @@
+// qpdo_small.hip -- fused solver for batches of small QPs on gfx950: ONE workgroup runs the complete
+// qpdo_setup (Ruiz scaling) + qpdo_warm_start + qpdo_solve loop of ONE problem in a single kernel launch
+// (BASELINE.json configs[2]: thousands of MPC-sized QPs, no collective).  A batch is a grid of such
+// workgroups; nothing returns to the host between passes.
+//
+// The arithmetic follows the reference's operation order step by step (the same restatement the CPU
+// oracle uses): row sums in ascending column order, 4-way grouped dot products (src/lin_alg.c:59-71),
+// natural-order left-looking LDL' of Q + sigma_f I + A' diag(d) A, column-oriented triangular solves,
+// stable sort of the linesearch breakpoints followed by the sequential walk of src/linesearch.c:126-157.
+// With -ffp-contract=off the results are therefore bit-identical to the oracle, not merely close.
+//
+// Work split inside the workgroup: elementwise passes and row sums are thread-parallel, reductions whose
+// order matters (dots, the breakpoint walk) run on one lane, the factorization is parallel over rows with
+// one barrier per column.  All vectors and the dense K (n x n) live in global memory (L2-resident at these
+// sizes); LDS holds the sort keys and reduction scratch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+
+#include "qpdo.h"
+#include "qpdo_amd_ext.h"
+#include "qpdo_dev.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define SM_THREADS 512
+#define SM_MAX_M 1024                    // 2m breakpoints are sorted in LDS
+#define SM_MAX_N 1024
+#define SM_INFTY 1e20
+#define SM_MAX_RANK_UPDATE 100
+
+struct SmallQP {
+    int n, m;
+    const int *Arp, *Aci; double *Aval;      // CSR(A), m rows, column-sorted
+    const int *Trp, *Tci; double *Tval;      // CSR(A'), n rows
+    const int *Qrp, *Qci; double *Qval;      // full symmetric CSR(Q)
+    double *q, *l, *u;                       // scaled in place
+    const double *x0, *y0;                   // warm start or NULL
+    double *nv;                              // n-vector workspace (NV_COUNT * n)
+    double *mv;                              // m-vector workspace (MV_COUNT * m)
+    double *lsv;                             // 2 * (2m): ls_delta, ls_alpha
+    int *iv;                                 // 3 * m ints: active, active_old, changed
+    double *K;                               // n * n, column-major, lower
+    double c_const;
+    // results
+    double *sol_x, *sol_y, *cert_dx, *cert_dy;
+    QPDOInfo info;
+    long newton_passes, factor_count;
+};
+enum { NV_X = 0, NV_XBAR, NV_QX, NV_ATY, NV_DF, NV_RD, NV_RDI, NV_RHS, NV_DX, NV_QDX, NV_ATDY, NV_D, NV_DINV, NV_T, NV_COUNT };
+enum { MV_Y = 0, MV_YBAR, MV_AX, MV_MU, MV_ISQ, MV_W, MV_RP, MV_RPOLD, MV_RPI, MV_DY, MV_ADX, MV_DW, MV_E, MV_EINV, MV_ATS, MV_T, MV_COUNT };
+
+#define FOR_T(i, N) for (int i = threadIdx.x; i < (N); i += blockDim.x)
+#define SYNC __syncthreads()
+
+__device__ __forceinline__ double s_abs(double x) { return x < 0 ? -x : x; }
+__device__ __forceinline__ double s_max(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double s_min(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double s_mid(double a, double lo, double hi) { return s_max(lo, s_min(a, hi)); }
+
+// block-wide max of non-negative values (order independent => exact); result to every thread
+__device__ double blk_max(double v, double *sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_down(v, o, 64); v = t > v ? t : v; }
+    SYNC;
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    SYNC;
+    double t = sm[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); i++) t = sm[i] > t ? sm[i] : t;
+    return t;
+}
+__device__ int blk_sum_int(int v, int *sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    SYNC;
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    SYNC;
+    int t = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += sm[i];
+    return t;
+}
+// inf-norm of a vector, or of a .* b when b != NULL (lin_alg.c:107-140: NaN never wins)
+__device__ double norm_inf(const double *a, const double *b, int n, double *sm) {
+    double mx = 0.0;
+    FOR_T(i, n) { double s = s_abs(b ? a[i] * b[i] : a[i]); mx = s > mx ? s : mx; }
+    return blk_max(mx, sm);
+}
+// lin_alg.c:59-71 on one lane; result broadcast through LDS
+__device__ double dot_seq(const double *a, const double *b, int n, double *sm) {
+    SYNC;
+    if (threadIdx.x == 0) {
+        double prod = 0.0; int i = 0;
+        if (n >= 4) for (; i <= n - 4; i += 4) prod += (a[i] * b[i] + a[i + 1] * b[i + 1] + a[i + 2] * b[i + 2] + a[i + 3] * b[i + 3]);
+        for (; i < n; i++) prod += a[i] * b[i];
+        sm[16] = prod;
+    }
+    SYNC;
+    return sm[16];
+}
+// y = M x, CSR, one thread per row, ascending columns (== the column-ordered CSC product of the reference)
+__device__ void spmv_rows(int nrows, const int *rp, const int *ci, const double *val, const double *x, double *y) {
+    FOR_T(r, nrows) {
+        double s = 0.0;
+        for (int k = rp[r]; k < rp[r + 1]; k++) s += val[k] * x[ci[k]];
+        y[r] = s;
+    }
+}
+
+// ---- Ruiz + cost scaling (scaling.c:24-91) ----------------------------------------------------------
+__device__ void small_scale(SmallQP &P, int iters, double *D, double *Dinv, double *E, double *Einv, double *tn, double *tm,
+                            double &c, double &cinv, double *sm) {
+    const int n = P.n, m = P.m;
+    FOR_T(i, n) D[i] = 1.0;
+    FOR_T(i, m) E[i] = 1.0;
+    SYNC;
+    for (int it = 0; it < iters; it++) {
+        FOR_T(j, n) { double mx = 0.0; for (int k = P.Trp[j]; k < P.Trp[j + 1]; k++) mx = s_max(s_abs(P.Tval[k]), mx); tn[j] = mx; }
+        FOR_T(i, m) { double mx = 0.0; for (int k = P.Arp[i]; k < P.Arp[i + 1]; k++) mx = s_max(s_abs(P.Aval[k]), mx); tm[i] = mx; }
+        SYNC;
+        FOR_T(j, n) { double v = tn[j]; v = v < 1e-9 ? 1.0 : v; v = sqrt(v); v = 1.0 / v; tn[j] = v; D[j] = D[j] * v; }
+        FOR_T(i, m) { double v = tm[i]; v = v < 1e-9 ? 1.0 : v; v = sqrt(v); v = 1.0 / v; tm[i] = v; E[i] = E[i] * v; }
+        SYNC;
+        FOR_T(i, m) for (int k = P.Arp[i]; k < P.Arp[i + 1]; k++) { double v = P.Aval[k]; v = v * tm[i]; v = v * tn[P.Aci[k]]; P.Aval[k] = v; }
+        FOR_T(j, n) for (int k = P.Trp[j]; k < P.Trp[j + 1]; k++) { double v = P.Tval[k]; v = v * tm[P.Tci[k]]; v = v * tn[j]; P.Tval[k] = v; }
+        SYNC;
+    }
+    FOR_T(r, n) for (int k = P.Qrp[r]; k < P.Qrp[r + 1]; k++) {
+        const int cc = P.Qci[k];
+        const double t = r >= cc ? D[cc] * D[r] : D[r] * D[cc];
+        P.Qval[k] *= t;
+    }
+    FOR_T(j, n) P.q[j] = D[j] * P.q[j];
+    SYNC;
+    const double nq = norm_inf(P.q, nullptr, n, sm);          // Qx = 0 at setup
+    c = 1 / s_max(1.0, nq);
+    FOR_T(j, n) P.q[j] *= c;
+    FOR_T(r, n) for (int k = P.Qrp[r]; k < P.Qrp[r + 1]; k++) P.Qval[k] *= c;
+    FOR_T(j, n) Dinv[j] = 1.0 / D[j];
+    FOR_T(i, m) Einv[i] = 1.0 / E[i];
+    cinv = 1.0 / c;
+    FOR_T(i, m) { P.l[i] = E[i] * P.l[i]; P.u[i] = E[i] * P.u[i]; }
+    SYNC;
+}
+
+// ---- dense system: assembly (one wave per column, sequential over rows: fixed order), left-looking LDL' ----
+__device__ void small_assemble(SmallQP &P, const double *dw, double sigma_f, double *accbuf) {
+    const int n = P.n;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    double *K = P.K;
+    double *acc = accbuf + (size_t)wave * n;       // LDS, private to the wave: in-order read-modify-writes
+    for (int j = wave; j < n; j += nw) {
+        for (int i = j + lane; i < n; i += 64) acc[i] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = P.Qrp[j] + lane; k < P.Qrp[j + 1]; k += 64) { const int i = P.Qci[k]; if (i >= j) acc[i] += P.Qval[k]; }
+        __builtin_amdgcn_wave_barrier();
+        for (int t = P.Trp[j]; t < P.Trp[j + 1]; t++) {
+            const int r = P.Tci[t];
+            const double wgt = dw[r];
+            if (wgt == 0.0) continue;
+            const double w = P.Tval[t] * wgt;
+            for (int e = P.Arp[r] + lane; e < P.Arp[r + 1]; e += 64) { const int i = P.Aci[e]; if (i >= j) acc[i] += w * P.Aval[e]; }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) acc[j] += sigma_f;
+        __builtin_amdgcn_wave_barrier();
+        double *col = K + (size_t)j * n;
+        for (int i = j + lane; i < n; i += 64) col[i] = acc[i];
+        __builtin_amdgcn_wave_barrier();
+    }
+    SYNC;
+}
+// left-looking by columns, natural order, no pivoting; K holds unit-lower L below and D on the diagonal
+__device__ void small_factor(SmallQP &P, double *tn) {
+    const int n = P.n;
+    double *K = P.K;
+    for (int j = 0; j < n; j++) {
+        double *cj = K + (size_t)j * n;
+        FOR_T(ii, n - j) {
+            const int i = j + ii;
+            double s = cj[i];
+            for (int k = 0; k < j; k++) {
+                const double ljk = K[j + (size_t)k * n];
+                if (ljk == 0.0) continue;
+                const double t = ljk * K[k + (size_t)k * n];
+                s -= K[i + (size_t)k * n] * t;
+            }
+            tn[i] = s;
+        }
+        SYNC;
+        const double inv = 1.0 / tn[j];
+        FOR_T(ii, n - j) { const int i = j + ii; cj[i] = (i == j) ? tn[j] : tn[i] * inv; }
+        SYNC;
+    }
+}
+__device__ void small_ldl_solve(SmallQP &P, const double *b, double *x) {
+    const int n = P.n;
+    const double *K = P.K;
+    FOR_T(i, n) x[i] = b[i];
+    SYNC;
+    for (int j = 0; j < n; j++) {                 // L z = b
+        const double xj = x[j];
+        const double *cj = K + (size_t)j * n;
+        SYNC;
+        FOR_T(ii, n - j - 1) { const int i = j + 1 + ii; x[i] -= cj[i] * xj; }
+        SYNC;
+    }
+    FOR_T(j, n) x[j] /= K[j + (size_t)j * n];
+    SYNC;
+    for (int j = n - 1; j >= 0; j--) {            // L' x = z, column oriented: x_j is final, eliminate it from the rows above
+        const double xj = x[j];
+        SYNC;
+        FOR_T(i, j) x[i] -= K[j + (size_t)i * n] * xj;
+        SYNC;
+    }
+}
+
+// ---- linesearch (linesearch.c:8-158) -------------------------------------------------------------------
+__device__ double small_linesearch(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, double *tm, double *sm, u64 *skey, u32 *sidx) {
+    const int n = P.n, m = P.m;
+    double *dy = V[MV_DY], *mu = V[MV_MU], *isq = V[MV_ISQ], *w = V[MV_W], *y = V[MV_Y], *Adx = V[MV_ADX];
+    FOR_T(i, m) { double s = dy[i] * mu[i]; s = s * 0.5; tm[i] = s; }
+    double eta = dot_seq(dy, tm, m, sm);
+    eta += dot_seq(P.nv + (size_t)NV_DX * n, P.nv + (size_t)NV_QDX * n, n, sm);
+    eta *= 0.5;
+    double beta = dot_seq(y, tm, m, sm);
+    beta += dot_seq(P.nv + (size_t)NV_DX * n, P.nv + (size_t)NV_DF * n, n, sm);
+    beta *= 0.5;
+    FOR_T(i, m) {
+        double c0 = Adx[i] - tm[i]; c0 = c0 * isq[i];
+        ls_delta[i + m] = c0; ls_delta[i] = c0 * -1.0;
+        ls_alpha[i] = (w[i] - P.l[i]) * isq[i];
+        ls_alpha[i + m] = (P.u[i] - w[i]) * isq[i];
+    }
+    SYNC;
+    // candidates: key = bits(t) for t > 0, sentinel otherwise; bitonic sort on (key, idx) == stable sort by t
+    const int M2 = 2 * m;
+    int np2 = 1; while (np2 < M2) np2 <<= 1;
+    FOR_T(i, np2) {
+        u64 key = ~0ull;
+        if (i < M2) { const double t = ls_alpha[i] / ls_delta[i]; if (t > 0) key = (u64)__double_as_longlong(t); }
+        skey[i] = key; sidx[i] = (u32)i;
+    }
+    SYNC;
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            FOR_T(i, np2) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const u64 ka = skey[i], kb = skey[ixj]; const u32 ia = sidx[i], ib = sidx[ixj];
+                    const bool up = ((i & k) == 0);
+                    const bool gt = (ka > kb) || (ka == kb && ia > ib);
+                    if (gt == up) { skey[i] = kb; skey[ixj] = ka; sidx[i] = ib; sidx[ixj] = ia; }
+                }
+            }
+            SYNC;
+        }
+    // J sums and the walk, sequentially on one lane (linesearch.c:108-157)
+    if (threadIdx.x == 0) {
+        double sa = 0.0, sb = 0.0; int nL = 0;
+        for (int i = 0; i < M2; i++) {
+            const double dl = ls_delta[i], t = ls_alpha[i] / dl;
+            const int L = t > 0, Pp = dl > 0;
+            nL += L;
+            if ((Pp + L) == 1) sa += dl * dl;
+        }
+        for (int i = 0; i < M2; i++) {
+            const double dl = ls_delta[i], al = ls_alpha[i], t = al / dl;
+            const int L = t > 0, Pp = dl > 0;
+            if ((Pp + L) == 1) sb += dl * al;
+        }
+        double a = eta + sa, b = beta - sb, tau;
+        if (nL == 0) tau = -b / a;
+        else {
+            const double t0 = __longlong_as_double((long long)skey[0]);
+            if (b + a * t0 > 0) tau = -b / a;
+            else {
+                int i = 0, iz; bool found = false;
+                while (i < nL - 1) {
+                    iz = (int)sidx[i];
+                    const double dl = ls_delta[iz], al = ls_alpha[iz];
+                    if (dl > 0) { a = a + dl * dl; b = b - dl * al; } else { a = a - dl * dl; b = b + dl * al; }
+                    i++;
+                    if (b + a * __longlong_as_double((long long)skey[i]) > 0) { found = true; break; }
+                }
+                if (!found) {
+                    iz = (int)sidx[i];
+                    const double dl = ls_delta[iz], al = ls_alpha[iz];
+                    if (dl > 0) { a = a + dl * dl; b = b - dl * al; } else { a = a - dl * dl; b = b + dl * al; }
+                }
+                tau = -b / a;
+            }
+        }
+        sm[17] = tau;
+    }
+    SYNC;
+    return sm[17];
+}
+
+__device__ void small_status(QPDOInfo &info, long st) {
+    info.status_val = st;
+    const char *s = "unrecognised status value";
+    switch (st) {
+        case QPDO_SOLVED: s = "solved"; break;
+        case QPDO_PRIMAL_INFEASIBLE: s = "primal infeasible"; break;
+        case QPDO_DUAL_INFEASIBLE: s = "dual infeasible"; break;
+        case QPDO_MAX_ITER_REACHED: s = "maximum iterations reached"; break;
+        case QPDO_NON_CVX: s = "unrecognised status value"; break;
+        case QPDO_UNSOLVED: s = "unsolved"; break;
+        case QPDO_ERROR: s = "error"; break;
+    }
+    int i = 0;
+    for (; s[i] && i < 31; i++) info.status[i] = s[i];
+    info.status[i] = 0;
+}
+
+// ---- the whole solve of one QP by one workgroup ----------------------------------------------------------
+__global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int count, QPDOSettings st) {
+    __shared__ double sm[32];
+    __shared__ u64 skey[2 * SM_MAX_M];
+    __shared__ u32 sidx[2 * SM_MAX_M];
+    extern __shared__ __attribute__((aligned(16))) double accbuf[];   // (threads/64) * max n doubles
+    if ((int)blockIdx.x >= count) return;
+    SmallQP &P = probs[blockIdx.x];
+    const int n = P.n, m = P.m;
+    double *NVp[NV_COUNT]; double *V[MV_COUNT];
+    for (int i = 0; i < NV_COUNT; i++) NVp[i] = P.nv + (size_t)i * n;
+    for (int i = 0; i < MV_COUNT; i++) V[i] = P.mv + (size_t)i * m;
+    double *x = NVp[NV_X], *xbar = NVp[NV_XBAR], *Qx = NVp[NV_QX], *Aty = NVp[NV_ATY], *df = NVp[NV_DF], *res_dual = NVp[NV_RD],
+           *res_dual_in = NVp[NV_RDI], *rhs = NVp[NV_RHS], *dx = NVp[NV_DX], *Qdx = NVp[NV_QDX], *Atdy = NVp[NV_ATDY], *D = NVp[NV_D],
+           *Dinv = NVp[NV_DINV], *tn = NVp[NV_T];
+    double *y = V[MV_Y], *ybar = V[MV_YBAR], *Ax = V[MV_AX], *mu = V[MV_MU], *isq = V[MV_ISQ], *w = V[MV_W], *res_prim = V[MV_RP],
+           *res_prim_old = V[MV_RPOLD], *res_prim_in = V[MV_RPI], *dy = V[MV_DY], *Adx = V[MV_ADX], *dw = V[MV_DW], *E = V[MV_E],
+           *Einv = V[MV_EINV], *ats = V[MV_ATS], *tm = V[MV_T];
+    int *active = P.iv, *active_old = P.iv + m, *changed = P.iv + 2 * m;
+    double *ls_delta = P.lsv, *ls_alpha = P.lsv + 2 * (size_t)m;
+    const int scaled = st.scaling > 0, prox = (int)st.proximal;
+    double sc_c = 1.0, sc_cinv = 1.0;
+
+    // ---- setup: workspace zero + scaling (qpdo.c:49-212) ----
+    FOR_T(i, NV_COUNT * n) P.nv[i] = 0.0;
+    FOR_T(i, MV_COUNT * m) P.mv[i] = 0.0;
+    FOR_T(i, 3 * m) P.iv[i] = 0;
+    SYNC;
+    if (scaled) small_scale(P, (int)st.scaling, D, Dinv, E, Einv, tn, tm, sc_c, sc_cinv, sm);
+
+    // ---- warm start (qpdo.c:217-299) + initialize_mu (iteration.c:98-122) ----
+    double sigma = st.sigma_init;
+    if (P.x0) {
+        FOR_T(i, n) { double v = P.x0[i]; if (scaled) v = v * Dinv[i]; x[i] = v; xbar[i] = v; }
+        SYNC;
+        spmv_rows(n, P.Qrp, P.Qci, P.Qval, x, Qdx);
+        spmv_rows(m, P.Arp, P.Aci, P.Aval, x, Ax);
+        SYNC;
+        FOR_T(i, n) Qx[i] = prox ? Qdx[i] + sigma * x[i] : Qdx[i];
+        SYNC;
+    }
+    if (P.y0) {
+        FOR_T(i, m) { double v = P.y0[i]; if (scaled) { v = v * Einv[i]; v = v * sc_c; } y[i] = v; ybar[i] = v; }
+        SYNC;
+        spmv_rows(n, P.Trp, P.Tci, P.Tval, y, Aty);
+        SYNC;
+    }
+    {
+        const double f = 0.5 * dot_seq(x, Qx, n, sm) + dot_seq(P.q, x, n, sm);
+        FOR_T(i, m) {
+            const double r = Ax[i] - s_mid(Ax[i], P.l[i], P.u[i]);
+            const double v = s_max(1e-3, s_min(1e3, 0.1 * s_max(1, 0.5 * r * r) / s_max(1, s_abs(f))));
+            mu[i] = v;
+            double s = sqrt(v); isq[i] = 1.0 / s;
+        }
+        SYNC;
+    }
+    const double isq_mu_min = 1 / sqrt(st.mu_min);
+
+    // ---- solve loop (qpdo.c:304-476) ----
+    double eps_in = st.eps_abs_in, tau = 0.0, sigma_f = 0.0;
+    sigma = st.sigma_init;
+    int reset_newton = 1, factor_valid = 0, last_branch = -1; double last_sigma_f = -1.0;
+    long iter = 0, oter = 0, iter_old = 0, status = QPDO_UNSOLVED, newton = 0, nfactor = 0;
+    double rpn = 0, rdn = 0, rpin = 0, rdin = 0;
+    for (iter = 0; iter < st.max_iter; iter++) {
+        // outer + inner residuals (iteration.c:30-93)
+        FOR_T(i, m) {
+            const double ax = Ax[i], yi = y[i];
+            double t;
+            if (scaled) { t = E[i] * yi; t = t * sc_cinv; t = E[i] * t; t = ax + t; } else t = ax + yi;
+            const double z = s_mid(t, P.l[i], P.u[i]);
+            res_prim[i] = ax - z;
+            const double wi = ax + mu[i] * (ybar[i] - 0.5 * yi);
+            w[i] = wi;
+            const double zin = s_mid(wi, P.l[i], P.u[i]);
+            res_prim_in[i] = ax + mu[i] * (ybar[i] - yi) - zin;
+        }
+        FOR_T(j, n) {
+            const double df0 = Qx[j] + P.q[j], aty = Aty[j];
+            double rd, dfi;
+            if (prox) { rd = df0 + (-sigma) * x[j]; rd = rd + aty; dfi = df0 + (-sigma) * xbar[j]; } else { rd = df0 + aty; dfi = df0; }
+            df[j] = dfi; res_dual[j] = rd; res_dual_in[j] = dfi + aty;
+        }
+        SYNC;
+        rpn = norm_inf(res_prim, scaled ? Einv : nullptr, m, sm);
+        rdn = norm_inf(res_dual, scaled ? Dinv : nullptr, n, sm); if (scaled) rdn *= sc_cinv;
+        rpin = norm_inf(res_prim_in, scaled ? Einv : nullptr, m, sm);
+        rdin = norm_inf(res_dual_in, scaled ? Dinv : nullptr, n, sm); if (scaled) rdin *= sc_cinv;
+        if ((rpn > SM_INFTY) || (rdn > SM_INFTY)) { status = QPDO_NON_CVX; break; }
+        if ((rpn <= st.eps_abs) && (rdn <= st.eps_abs)) { status = QPDO_SOLVED; break; }
+        const int inner_opt = (rpin <= eps_in) && (rdin <= eps_in);
+        if (((iter > iter_old + 1) && inner_opt) || (iter == iter_old + st.inner_max_iter)) {
+            if (iter < iter_old + st.inner_max_iter) {
+                if (st.eps_prim_inf > 0) {           // termination.c:97-151
+                    FOR_T(i, m) dy[i] = y[i] - ybar[i];
+                    SYNC;
+                    spmv_rows(n, P.Trp, P.Tci, P.Tval, dy, Atdy);
+                    SYNC;
+                    const double eps = st.eps_prim_inf * norm_inf(dy, scaled ? E : nullptr, m, sm);
+                    if (eps != 0) {
+                        if (scaled) { FOR_T(j, n) Atdy[j] = Dinv[j] * Atdy[j]; }
+                        SYNC;
+                        if (threadIdx.x == 0) {
+                            double oob = 0;
+                            for (int i = 0; i < m; i++) {
+                                const double e = scaled ? E[i] : 1.0;
+                                oob += (P.u[i] < e * SM_INFTY) ? P.u[i] * s_max(dy[i], 0) : 0;
+                                oob += (P.l[i] > -e * SM_INFTY) ? P.l[i] * s_min(dy[i], 0) : 0;
+                            }
+                            sm[18] = oob;
+                        }
+                        SYNC;
+                        const double oob = sm[18];
+                        const double nat = norm_inf(Atdy, nullptr, n, sm);
+                        if ((nat <= eps) && (oob <= -eps)) {
+                            status = QPDO_PRIMAL_INFEASIBLE;
+                            if (scaled) { FOR_T(i, m) { double v = dy[i] * sc_cinv; dy[i] = E[i] * v; } }
+                            SYNC;
+                            break;
+                        }
+                    }
+                }
+                if (st.eps_dual_inf > 0) {           // termination.c:156-216
+                    FOR_T(j, n) dx[j] = x[j] - xbar[j];
+                    SYNC;
+                    spmv_rows(n, P.Qrp, P.Qci, P.Qval, dx, Qdx);
+                    spmv_rows(m, P.Arp, P.Aci, P.Aval, dx, Adx);
+                    SYNC;
+                    const double eps = st.eps_dual_inf * norm_inf(dx, scaled ? D : nullptr, n, sm);
+                    if (eps != 0) {
+                        int viol = 0;
+                        FOR_T(k, m) {
+                            double v = Adx[k]; const double e = scaled ? E[k] : 1.0;
+                            if (scaled) { v = Einv[k] * v; Adx[k] = v; }
+                            if ((P.u[k] < e * SM_INFTY && v >= eps) || (P.l[k] > -e * SM_INFTY && v <= -eps)) viol = 1;
+                        }
+                        viol = blk_sum_int(viol, (int *)sm);
+                        if (!viol) {
+                            if (prox) { FOR_T(j, n) Qdx[j] = Qdx[j] + (-sigma * tau) * dx[j]; }
+                            SYNC;
+                            const double nq = norm_inf(Qdx, nullptr, n, sm);
+                            const double qdx = dot_seq(P.q, dx, n, sm);
+                            const double cc = scaled ? sc_c : 1.0;
+                            if ((nq <= cc * eps) && (qdx <= -cc * eps)) {
+                                status = QPDO_DUAL_INFEASIBLE;
+                                if (scaled) { FOR_T(j, n) dx[j] = D[j] * dx[j]; }
+                                SYNC;
+                                break;
+                            }
+                        }
+                    }
+                }
+            }
+            FOR_T(j, n) xbar[j] = x[j];
+            FOR_T(i, m) ybar[i] = y[i];
+            SYNC;
+            if ((oter > 0) && (rpn > st.eps_abs)) {   // update_mu (iteration.c:127-168)
+                const double rn = norm_inf(res_prim, nullptr, m, sm);
+                int cnt = 0;
+                FOR_T(k, m) {
+                    int ch = 0;
+                    if (s_abs(res_prim[k]) > s_max(st.eps_abs, st.theta * s_abs(res_prim_old[k]))) {
+                        double mu_factor = 1.0 / s_min(1.0, st.delta * rn / s_abs(res_prim[k]));
+                        const double mu_new = mu[k] / mu_factor;
+                        if (mu_new >= st.mu_min) {
+                            if (mu[k] != mu_new) ch = 1;
+                            mu[k] = mu_new; mu_factor = sqrt(mu_factor); isq[k] = mu_factor * isq[k]; ats[k] = mu_factor;
+                        } else {
+                            if (mu[k] != st.mu_min) ch = 1;
+                            mu[k] = st.mu_min; ats[k] = isq_mu_min / isq[k]; isq[k] = isq_mu_min;
+                        }
+                    } else ats[k] = 1.0;
+                    changed[k] = ch; cnt += ch;
+                }
+                cnt = blk_sum_int(cnt, (int *)sm);
+                if ((prox && sigma > st.sigma_min) || (cnt > 0.25 * SM_MAX_RANK_UPDATE)) reset_newton = 1;
+                else if (cnt > 0) {
+                    FOR_T(k, m) if (changed[k]) { const double s = sqrt(1 - 1 / (ats[k] * ats[k])); const double col = isq[k] * s; dw[k] += col * col; }
+                    factor_valid = 0;
+                    SYNC;
+                }
+            }
+            if (prox && (oter > 0) && (rdn > st.eps_abs)) {   // update_sigma (iteration.c:173-180)
+                if (sigma > st.sigma_min) {
+                    const double old = sigma;
+                    sigma = s_max(sigma * st.sigma_upd, st.sigma_min);
+                    reset_newton = 1;
+                    FOR_T(j, n) Qx[j] = Qx[j] + (sigma - old) * x[j];
+                    SYNC;
+                }
+            }
+            if (iter < iter_old + st.inner_max_iter) eps_in = s_max(st.rho * eps_in, 0.1 * st.eps_abs);
+            FOR_T(i, m) res_prim_old[i] = res_prim[i];
+            SYNC;
+            oter++; iter_old = iter;
+        } else {
+            if (st.reset_newton_iter > 0 && (iter % st.reset_newton_iter == 0)) reset_newton = 1;
+            // active set, enter / leave (newton.c:96-126)
+            int na = 0, ne = 0, nl = 0;
+            FOR_T(i, m) {
+                const int act = (w[i] <= P.l[i]) || (w[i] >= P.u[i]);
+                active[i] = act; na += act; ne += (act && !active_old[i]); nl += (!act && active_old[i]);
+            }
+            na = blk_sum_int(na, (int *)sm); ne = blk_sum_int(ne, (int *)sm); nl = blk_sum_int(nl, (int *)sm);
+            int branch;
+            if ((reset_newton && na) || (ne + nl) > SM_MAX_RANK_UPDATE) { reset_newton = 0; branch = 0; }
+            else if (na) branch = 1; else branch = 2;
+            if (branch == 0 || branch == 2) sigma_f = prox ? sigma : 0.0;
+            FOR_T(i, m) {
+                const double wgt = isq[i] * isq[i];
+                if (branch == 0) dw[i] = active[i] ? wgt : 0.0;
+                else if (branch == 1) { if (active[i] && !active_old[i]) dw[i] += wgt; else if (!active[i] && active_old[i]) dw[i] -= wgt; }
+                else dw[i] = 0.0;
+                double t = res_prim_in[i] / mu[i];
+                if (!active[i]) t *= 2;
+                dy[i] = t;
+            }
+            if (branch == 0) factor_valid = 0;
+            else if (branch == 1) { if (ne + nl > 0) factor_valid = 0; }
+            else if (!(last_branch == 2 && last_sigma_f == sigma_f)) factor_valid = 0;
+            SYNC;
+            spmv_rows(n, P.Trp, P.Tci, P.Tval, dy, Atdy);
+            SYNC;
+            FOR_T(j, n) rhs[j] = -res_dual_in[j] - Atdy[j];
+            SYNC;
+            if (!factor_valid) { small_assemble(P, dw, sigma_f, accbuf); small_factor(P, tn); factor_valid = 1; nfactor++; }
+            last_branch = branch; last_sigma_f = sigma_f;
+            small_ldl_solve(P, rhs, dx);
+            spmv_rows(n, P.Qrp, P.Qci, P.Qval, dx, Qdx);
+            spmv_rows(m, P.Arp, P.Aci, P.Aval, dx, Adx);
+            SYNC;
+            if (prox) { FOR_T(j, n) Qdx[j] = Qdx[j] + sigma * dx[j]; }
+            FOR_T(i, m) { if (active[i]) dy[i] += (Adx[i] / mu[i]); active_old[i] = active[i]; }
+            SYNC;
+            spmv_rows(n, P.Trp, P.Tci, P.Tval, dy, Atdy);
+            SYNC;
+            tau = small_linesearch(P, V, ls_delta, ls_alpha, tm, sm, skey, sidx);
+            FOR_T(j, n) { x[j] = x[j] + tau * dx[j]; Qx[j] = Qx[j] + tau * Qdx[j]; Aty[j] = Aty[j] + tau * Atdy[j]; }
+            FOR_T(i, m) { y[i] = y[i] + tau * dy[i]; Ax[i] = Ax[i] + tau * Adx[i]; }
+            SYNC;
+            newton++;
+        }
+    }
+    if (status == QPDO_UNSOLVED) status = QPDO_MAX_ITER_REACHED;
+    // store_solution (termination.c:82-92) + objective (iteration.c:185-221)
+    FOR_T(j, n) P.sol_x[j] = scaled ? x[j] * D[j] : x[j];
+    FOR_T(i, m) { if (scaled) { const double v = y[i] * sc_cinv; y[i] = v; P.sol_y[i] = v * E[i]; } else P.sol_y[i] = y[i]; }
+    FOR_T(j, n) P.cert_dx[j] = dx[j];
+    FOR_T(i, m) P.cert_dy[i] = dy[i];
+    SYNC;
+    if (threadIdx.x == 0) {
+        double obj = 0; int i = 0;
+        if (prox) {
+            if (n >= 4) for (; i <= n - 4; i += 4)
+                obj += (0.5 * (Qx[i] - x[i] * sigma) + P.q[i]) * x[i] + (0.5 * (Qx[i + 1] - x[i + 1] * sigma) + P.q[i + 1]) * x[i + 1] +
+                       (0.5 * (Qx[i + 2] - x[i + 2] * sigma) + P.q[i + 2]) * x[i + 2] + (0.5 * (Qx[i + 3] - x[i + 3] * sigma) + P.q[i + 3]) * x[i + 3];
+            for (; i < n; i++) obj += (0.5 * (Qx[i] - sigma * x[i]) + P.q[i]) * x[i];
+        } else {
+            if (n >= 4) for (; i <= n - 4; i += 4)
+                obj += (0.5 * Qx[i] + P.q[i]) * x[i] + (0.5 * Qx[i + 1] + P.q[i + 1]) * x[i + 1] + (0.5 * Qx[i + 2] + P.q[i + 2]) * x[i + 2] +
+                       (0.5 * Qx[i + 3] + P.q[i + 3]) * x[i + 3];
+            for (; i < n; i++) obj += (0.5 * Qx[i] + P.q[i]) * x[i];
+        }
+        if (scaled) obj *= sc_cinv;
+        obj += P.c_const;
+        P.info.iterations = iter; P.info.oterations = oter;
+        P.info.res_prim_norm = rpn; P.info.res_dual_norm = rdn; P.info.res_prim_in_norm = rpin; P.info.res_dual_in_norm = rdin;
+        P.info.objective = obj;
+        small_status(P.info, status);
+        P.newton_passes = newton; P.factor_count = nfactor;
+    }
+}
+
+// ================================================================================================
+// host side: pack a batch into one arena, one upload, one launch, one download
+// ================================================================================================
+static thread_local char s_err[256] = "";
+#define SHIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { snprintf(s_err, sizeof(s_err), "%s: %s", #call, hipGetErrorString(e__)); rc = -1; goto done; } } while (0)
+
+struct HostCsr32 { std::vector<int> rp, ci; std::vector<double> val; };
+static inline long long idx_at(const void *a, int itype, long long k) { return itype == 0 ? (long long)((const int *)a)[k] : (long long)((const long long *)a)[k]; }
+static void csc_to_csr32(const cholmod_sparse *M, HostCsr32 &o) {          // CSR of the matrix itself
+    const long long nr = (long long)M->nrow, nc = (long long)M->ncol, nnz = idx_at(M->p, M->itype, nc);
+    o.rp.assign(nr + 1, 0); o.ci.resize(nnz); o.val.resize(nnz);
+    for (long long k = 0; k < nnz; k++) o.rp[idx_at(M->i, M->itype, k) + 1]++;
+    for (long long i = 0; i < nr; i++) o.rp[i + 1] += o.rp[i];
+    std::vector<int> next(o.rp.begin(), o.rp.end() - 1);
+    const double *x = (const double *)M->x;
+    for (long long j = 0; j < nc; j++)
+        for (long long k = idx_at(M->p, M->itype, j); k < idx_at(M->p, M->itype, j + 1); k++) { const int s = next[idx_at(M->i, M->itype, k)]++; o.ci[s] = (int)j; o.val[s] = x[k]; }
+}
+static void csc_as_csrT32(const cholmod_sparse *M, HostCsr32 &o) {         // CSR of the transpose = the CSC arrays
+    const long long nc = (long long)M->ncol, nnz = idx_at(M->p, M->itype, nc);
+    o.rp.resize(nc + 1); o.ci.resize(nnz); o.val.resize(nnz);
+    for (long long j = 0; j <= nc; j++) o.rp[j] = (int)idx_at(M->p, M->itype, j);
+    for (long long k = 0; k < nnz; k++) o.ci[k] = (int)idx_at(M->i, M->itype, k);
+    if (nnz) memcpy(o.val.data(), M->x, (size_t)nnz * 8);
+}
+static void sym_full32(const cholmod_sparse *Q, HostCsr32 &o) {            // full symmetric CSR, rows column-sorted
+    const int st = Q->stype;
+    if (st == 0) { csc_as_csrT32(Q, o); return; }
+    const long long n = (long long)Q->ncol;
+    std::vector<std::vector<std::pair<int, double>>> rows((size_t)n);
+    const double *x = (const double *)Q->x;
+    for (long long j = 0; j < n; j++)
+        for (long long k = idx_at(Q->p, Q->itype, j); k < idx_at(Q->p, Q->itype, j + 1); k++) {
+            const long long i = idx_at(Q->i, Q->itype, k);
+            if (i == j) rows[(size_t)i].push_back({(int)j, x[k]});
+            else if ((st < 0 && i > j) || (st > 0 && i < j)) { rows[(size_t)i].push_back({(int)j, x[k]}); rows[(size_t)j].push_back({(int)i, x[k]}); }
+        }
+    o.rp.assign(n + 1, 0);
+    for (long long r = 0; r < n; r++) {
+        std::stable_sort(rows[(size_t)r].begin(), rows[(size_t)r].end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.first < b.first; });
+        o.rp[r + 1] = o.rp[r] + (int)rows[(size_t)r].size();
+    }
+    o.ci.resize(o.rp[n]); o.val.resize(o.rp[n]);
+    for (long long r = 0; r < n; r++) { int s = o.rp[r]; for (auto &e : rows[(size_t)r]) { o.ci[s] = e.first; o.val[s] = e.second; s++; } }
+}
+
+extern "C" {
+
+const char *qdev_small_last_error(void) { return s_err; }
+
+// 1 if every item fits the fused kernel
+int qdev_small_eligible(long count, const void *items_) {
+    const QPDOAmdBatchItem *items = (const QPDOAmdBatchItem *)items_;
+    for (long i = 0; i < count; i++) {
+        const QPDOData *d = items[i].data;
+        if (!d || !d->Q || !d->A) return 0;
+        if (d->n < 1 || d->n > SM_MAX_N || d->m > SM_MAX_M) return 0;
+        if ((d->Q->itype != 0 && d->Q->itype != 2) || (d->A->itype != 0 && d->A->itype != 2)) return 0;
+        if (d->Q->xtype != 1 || d->A->xtype != 1 || d->Q->dtype != 0 || d->A->dtype != 0) return 0;
+    }
+    return 1;
+}
+
+// Solve all items with the fused kernel on `device`.  Returns 0 on success.
+int qdev_small_batch(int device, long count, void *items_, const void *settings_) {
+    QPDOAmdBatchItem *items = (QPDOAmdBatchItem *)items_;
+    const QPDOSettings *settings = (const QPDOSettings *)settings_;
+    int rc = 0;
+    char *dbase = nullptr; hipStream_t stream = nullptr; SmallQP *dprobs = nullptr;
+    std::vector<char> harena; std::vector<SmallQP> hp((size_t)count);
+    std::vector<size_t> off_solx((size_t)count), off_soly((size_t)count), off_dx((size_t)count), off_dy((size_t)count);
+    size_t total = 0;
+    auto reserve = [&](size_t bytes) { size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; };
+    struct Lay { size_t Arp, Aci, Aval, Trp, Tci, Tval, Qrp, Qci, Qval, q, l, u, x0, y0, nv, mv, lsv, iv, K, solx, soly, dx, dy; HostCsr32 A, T, Q; };
+    std::vector<Lay> lay((size_t)count);
+    for (long i = 0; i < count; i++) {
+        const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
+        const size_t n = d->n, m = d->m;
+        csc_to_csr32(d->A, L.A); csc_as_csrT32(d->A, L.T); sym_full32(d->Q, L.Q);
+        L.Arp = reserve((m + 1) * 4); L.Aci = reserve(L.A.ci.size() * 4 + 4); L.Aval = reserve(L.A.val.size() * 8 + 8);
+        L.Trp = reserve((n + 1) * 4); L.Tci = reserve(L.T.ci.size() * 4 + 4); L.Tval = reserve(L.T.val.size() * 8 + 8);
+        L.Qrp = reserve((n + 1) * 4); L.Qci = reserve(L.Q.ci.size() * 4 + 4); L.Qval = reserve(L.Q.val.size() * 8 + 8);
+        L.q = reserve(n * 8); L.l = reserve(m * 8 + 8); L.u = reserve(m * 8 + 8);
+        L.x0 = items[i].x0 ? reserve(n * 8) : (size_t)-1; L.y0 = items[i].y0 ? reserve(m * 8 + 8) : (size_t)-1;
+        L.solx = reserve(n * 8); L.soly = reserve(m * 8 + 8); L.dx = reserve(n * 8); L.dy = reserve(m * 8 + 8);
+    }
+    const size_t upload_bytes = total;       // everything above is input or output; the rest is scratch
+    for (long i = 0; i < count; i++) {
+        const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
+        const size_t n = d->n, m = d->m;
+        L.nv = reserve((size_t)NV_COUNT * n * 8); L.mv = reserve((size_t)MV_COUNT * m * 8 + 8); L.lsv = reserve(4 * m * 8 + 8);
+        L.iv = reserve(3 * m * 4 + 4); L.K = reserve(n * n * 8);
+    }
+    harena.assign(upload_bytes, 0);
+    for (long i = 0; i < count; i++) {
+        const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
+        const size_t n = d->n, m = d->m;
+        char *h = harena.data();
+        memcpy(h + L.Arp, L.A.rp.data(), (m + 1) * 4); if (!L.A.ci.empty()) { memcpy(h + L.Aci, L.A.ci.data(), L.A.ci.size() * 4); memcpy(h + L.Aval, L.A.val.data(), L.A.val.size() * 8); }
+        memcpy(h + L.Trp, L.T.rp.data(), (n + 1) * 4); if (!L.T.ci.empty()) { memcpy(h + L.Tci, L.T.ci.data(), L.T.ci.size() * 4); memcpy(h + L.Tval, L.T.val.data(), L.T.val.size() * 8); }
+        memcpy(h + L.Qrp, L.Q.rp.data(), (n + 1) * 4); if (!L.Q.ci.empty()) { memcpy(h + L.Qci, L.Q.ci.data(), L.Q.ci.size() * 4); memcpy(h + L.Qval, L.Q.val.data(), L.Q.val.size() * 8); }
+        memcpy(h + L.q, d->q, n * 8); if (m) { memcpy(h + L.l, d->l, m * 8); memcpy(h + L.u, d->u, m * 8); }
+        if (items[i].x0) memcpy(h + L.x0, items[i].x0, n * 8);
+        if (items[i].y0 && m) memcpy(h + L.y0, items[i].y0, m * 8);
+    }
+    SHIP(hipSetDevice(device));
+    SHIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    SHIP(hipMalloc((void **)&dbase, total));
+    SHIP(hipMalloc((void **)&dprobs, (size_t)count * sizeof(SmallQP)));
+    SHIP(hipMemcpyAsync(dbase, harena.data(), upload_bytes, hipMemcpyHostToDevice, stream));
+    for (long i = 0; i < count; i++) {
+        const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i]; SmallQP &p = hp[(size_t)i];
+        memset(&p, 0, sizeof(p));
+        p.n = (int)d->n; p.m = (int)d->m; p.c_const = d->c;
+        p.Arp = (const int *)(dbase + L.Arp); p.Aci = (const int *)(dbase + L.Aci); p.Aval = (double *)(dbase + L.Aval);
+        p.Trp = (const int *)(dbase + L.Trp); p.Tci = (const int *)(dbase + L.Tci); p.Tval = (double *)(dbase + L.Tval);
+        p.Qrp = (const int *)(dbase + L.Qrp); p.Qci = (const int *)(dbase + L.Qci); p.Qval = (double *)(dbase + L.Qval);
+        p.q = (double *)(dbase + L.q); p.l = (double *)(dbase + L.l); p.u = (double *)(dbase + L.u);
+        p.x0 = items[i].x0 ? (const double *)(dbase + L.x0) : nullptr; p.y0 = items[i].y0 ? (const double *)(dbase + L.y0) : nullptr;
+        p.nv = (double *)(dbase + L.nv); p.mv = (double *)(dbase + L.mv); p.lsv = (double *)(dbase + L.lsv); p.iv = (int *)(dbase + L.iv);
+        p.K = (double *)(dbase + L.K);
+        p.sol_x = (double *)(dbase + L.solx); p.sol_y = (double *)(dbase + L.soly); p.cert_dx = (double *)(dbase + L.dx); p.cert_dy = (double *)(dbase + L.dy);
+    }
+    SHIP(hipMemcpyAsync(dprobs, hp.data(), (size_t)count * sizeof(SmallQP), hipMemcpyHostToDevice, stream));
+    {
+        size_t nmax = 1;
+        for (long i = 0; i < count; i++) if (items[i].data->n > nmax) nmax = items[i].data->n;
+        const size_t lds = (SM_THREADS / 64) * nmax * sizeof(double);
+        SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        hipLaunchKernelGGL(k_small_solve, dim3((unsigned)count), dim3(SM_THREADS), lds, stream, dprobs, (int)count, *settings);
+    }
+    SHIP(hipGetLastError());
+    SHIP(hipMemcpyAsync(hp.data(), dprobs, (size_t)count * sizeof(SmallQP), hipMemcpyDeviceToHost, stream));
+    SHIP(hipMemcpyAsync(harena.data(), dbase, upload_bytes, hipMemcpyDeviceToHost, stream));
+    SHIP(hipStreamSynchronize(stream));
+    for (long i = 0; i < count; i++) {
+        const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
+        const size_t n = d->n, m = d->m;
+        items[i].info = hp[(size_t)i].info;
+        const long stv = items[i].info.status_val;
+        const double *sx = (const double *)(harena.data() + L.solx), *sy = (const double *)(harena.data() + L.soly);
+        const bool infeasible = (stv == QPDO_PRIMAL_INFEASIBLE) || (stv == QPDO_DUAL_INFEASIBLE);
+        if (items[i].x) for (size_t k = 0; k < n; k++) items[i].x[k] = infeasible ? NAN : sx[k];
+        if (items[i].y) for (size_t k = 0; k < m; k++) items[i].y[k] = infeasible ? NAN : sy[k];
+    }
+done:
+    if (dbase) hipFree(dbase);
+    if (dprobs) hipFree(dprobs);
+    if (stream) hipStreamDestroy(stream);
+    return rc;
+}
+
+}  // extern "C"

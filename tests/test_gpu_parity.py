@@ -215,10 +215,17 @@ def test_config2_full_size_properties(gpu_required):
     assert np.abs(r["y"][inside]).max() <= 1e-5
 
 
-def test_batch_of_mpc_sized_qps_matches_oracle(gpu_required):
-    """BASELINE.json configs[2] (n=120, m=360 with equality rows), a slice of the batch: every item must match
-    the oracle exactly in status / iterations / oterations, and concurrent workspaces must not interfere."""
-    probs = [problems.config_qp("C3", i) for i in range(24)]
+@pytest.mark.parametrize("mode", ["fused", "threads"])
+def test_batch_of_mpc_sized_qps_matches_oracle(mode, gpu_required, monkeypatch):
+    """BASELINE.json configs[2] (n=120, m=360 with equality rows), a slice of the batch, plus other small
+    shapes and the three reference known-answer QPs in the same batch.  Every item must match the oracle in
+    status / iterations / oterations; the fused one-workgroup-per-QP kernel follows the oracle's operation
+    order exactly, so its iterates are required to be BIT-IDENTICAL."""
+    if mode == "threads":
+        monkeypatch.setenv("QPDO_BATCH", "threads")
+    probs = [problems.config_qp("C3", i) for i in range(20)]
+    probs += [problems.config_qp("C1b", 0), problems.random_qp(26, 64, 1, 0.2), problems.random_qp(27, 1, 5, 1.0),
+              problems.random_qp(23, 150, 300, 0.05, 50)]
     res, failed = solver.solve_batch(probs, nthreads=8, verbose=0)
     assert failed == 0
     for p, r in zip(probs, res):
@@ -226,5 +233,22 @@ def test_batch_of_mpc_sized_qps_matches_oracle(gpu_required):
         ro = o.solve()
         assert (r["info"]["status_val"], r["info"]["iterations"], r["info"]["oterations"]) == \
                (ro["info"]["status_val"], ro["info"]["iterations"], ro["info"]["oterations"])
-        assert close_vec(r["x"], ro["x"]) and close_vec(r["y"], ro["y"])
+        if mode == "fused":
+            assert np.array_equal(r["x"], ro["x"]) and np.array_equal(r["y"], ro["y"])
+            assert r["info"]["objective"] == ro["info"]["objective"]
+            assert r["info"]["res_prim_norm"] == ro["info"]["res_prim_norm"]
+        else:
+            assert close_vec(r["x"], ro["x"]) and close_vec(r["y"], ro["y"])
+        o.close()
+
+
+def test_fused_batch_known_answers(gpu_required):
+    """reference examples/infeasibility_tests.m through the fused batch kernel"""
+    probs = [problems.infeasibility_kat(c) for c in ("degenerate", "primal_infeasible", "dual_infeasible")]
+    res, failed = solver.solve_batch(probs, verbose=0, max_iter=100)
+    assert failed == 0
+    assert [r["info"]["status_val"] for r in res] == [1, -3, -4]
+    for p, r in zip(probs, res):
+        o = ob.OracleSolver(p, ob.default_settings(max_iter=100)); ro = o.solve()
+        assert (r["info"]["iterations"], r["info"]["oterations"]) == (ro["info"]["iterations"], ro["info"]["oterations"])
         o.close()
