@@ -67,7 +67,7 @@ void qpdo_gen_problem(uint64_t seed, int64_t n, int64_t m, double density, int64
                       double *q, double *l, double *u) {
     const int64_t K = qpdo_gen_A_per_col(m, density);
     for (int64_t j = 0; j <= n; j++) Ap[j] = j * K;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n * K > 200000)
     for (int64_t j = 0; j < n; j++) {
         for (int64_t k = 0; k < K; k++) {
             int64_t lo = (k * m) / K, hi = ((k + 1) * m) / K;     /* stratum [lo,hi) */
@@ -81,7 +81,7 @@ void qpdo_gen_problem(uint64_t seed, int64_t n, int64_t m, double density, int64
     Qp[0] = 0;
     for (int64_t j = 0; j < n; j++) Qp[j + 1] = Qp[j] + 1 + q_col_count(n, j, density);
     const double s = 1.0 / sqrt(fmax(1.0, density * (double)n));
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for schedule(dynamic, 64) if (Qp[n] > 200000)
     for (int64_t j = 0; j < n; j++) {
         int64_t base = Qp[j], Kj = Qp[j + 1] - Qp[j] - 1, avail = n - 1 - j;
         Qi[base] = j; Qx[base] = 0.0;

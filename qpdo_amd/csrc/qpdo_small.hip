@@ -148,80 +148,81 @@ __device__ void small_scale(SmallQP &P, int iters, double *D, double *Dinv, doub
     SYNC;
 }
 
-// ---- dense system: assembly (one wave per column, sequential over rows: fixed order), left-looking LDL' ----
-__device__ void small_assemble(SmallQP &P, const double *dw, double sigma_f, double *accbuf) {
-    const int n = P.n;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    double *K = P.K;
-    double *acc = accbuf + (size_t)wave * n;       // LDS, private to the wave: in-order read-modify-writes
-    for (int j = wave; j < n; j += nw) {
-        for (int i = j + lane; i < n; i += 64) acc[i] = 0.0;
-        __builtin_amdgcn_wave_barrier();
-        for (int k = P.Qrp[j] + lane; k < P.Qrp[j + 1]; k += 64) { const int i = P.Qci[k]; if (i >= j) acc[i] += P.Qval[k]; }
-        __builtin_amdgcn_wave_barrier();
-        for (int t = P.Trp[j]; t < P.Trp[j + 1]; t++) {
-            const int r = P.Tci[t];
-            const double wgt = dw[r];
-            if (wgt == 0.0) continue;
-            const double w = P.Tval[t] * wgt;
-            for (int e = P.Arp[r] + lane; e < P.Arp[r + 1]; e += 64) { const int i = P.Aci[e]; if (i >= j) acc[i] += w * P.Aval[e]; }
-            __builtin_amdgcn_wave_barrier();
+// ---- dense system -----------------------------------------------------------------------------------------
+// K is addressed as K[koff(j) + i] (i >= j).  When the packed lower triangle fits in LDS it lives there
+// (koff = j*n - j(j+1)/2), otherwise in global memory as a full column-major square (koff = j*n).
+struct KView {
+    double *K; int n; int packed;
+    __device__ __forceinline__ size_t off(int j) const { return packed ? (size_t)j * n - (size_t)j * (j + 1) / 2 : (size_t)j * n; }
+    __device__ __forceinline__ double &at(int i, int j) const { return K[off(j) + i]; }
+};
+// assembly in the oracle's order: Q first, then rows r of A ascending (all threads share one row: every (i,j)
+// target of a row is distinct, rows are separated by a barrier), sigma_f last
+__device__ void small_assemble(SmallQP &P, const KView &kv, const double *dw, double sigma_f) {
+    const int n = P.n, m = P.m;
+    const size_t tot = kv.packed ? (size_t)n * (n + 1) / 2 : (size_t)n * n;
+    for (size_t i = threadIdx.x; i < tot; i += blockDim.x) kv.K[i] = 0.0;
+    SYNC;
+    FOR_T(r, n) for (int k = P.Qrp[r]; k < P.Qrp[r + 1]; k++) { const int cc = P.Qci[k]; if (r >= cc) kv.at(r, cc) += P.Qval[k]; }
+    SYNC;
+    for (int r = 0; r < m; r++) {
+        const double wgt = dw[r];
+        if (wgt == 0.0) continue;
+        const int b = P.Arp[r], len = P.Arp[r + 1] - b;
+        // pairs (a <= bb) of the row's entries: columns ascending, so Aci[b+bb] >= Aci[b+a]
+        for (int pidx = threadIdx.x; pidx < len * len; pidx += blockDim.x) {
+            const int a = pidx / len, bb = pidx % len;
+            if (bb >= a) { const double vj = P.Aval[b + a] * wgt; kv.at(P.Aci[b + bb], P.Aci[b + a]) += vj * P.Aval[b + bb]; }
         }
-        if (lane == 0) acc[j] += sigma_f;
-        __builtin_amdgcn_wave_barrier();
-        double *col = K + (size_t)j * n;
-        for (int i = j + lane; i < n; i += 64) col[i] = acc[i];
-        __builtin_amdgcn_wave_barrier();
+        SYNC;
     }
+    FOR_T(j, n) kv.at(j, j) += sigma_f;
     SYNC;
 }
 // left-looking by columns, natural order, no pivoting; K holds unit-lower L below and D on the diagonal
-__device__ void small_factor(SmallQP &P, double *tn) {
+__device__ void small_factor(SmallQP &P, const KView &kv, double *colbuf, double *tk) {
     const int n = P.n;
-    double *K = P.K;
     for (int j = 0; j < n; j++) {
-        double *cj = K + (size_t)j * n;
+        // t_k = l_jk d_k for k < j.  The reference skips k when l_jk == 0; subtracting x * 0 leaves the sum
+        // bit-for-bit unchanged, so the branch-free form below gives identical results.
+        FOR_T(k, j) tk[k] = kv.at(j, k) * kv.at(k, k);
+        SYNC;
         FOR_T(ii, n - j) {
             const int i = j + ii;
-            double s = cj[i];
-            for (int k = 0; k < j; k++) {
-                const double ljk = K[j + (size_t)k * n];
-                if (ljk == 0.0) continue;
-                const double t = ljk * K[k + (size_t)k * n];
-                s -= K[i + (size_t)k * n] * t;
-            }
-            tn[i] = s;
+            double s = kv.at(i, j);
+#pragma unroll 4
+            for (int k = 0; k < j; k++) s -= kv.at(i, k) * tk[k];
+            colbuf[i] = s;
         }
         SYNC;
-        const double inv = 1.0 / tn[j];
-        FOR_T(ii, n - j) { const int i = j + ii; cj[i] = (i == j) ? tn[j] : tn[i] * inv; }
+        const double inv = 1.0 / colbuf[j];
+        FOR_T(ii, n - j) { const int i = j + ii; kv.at(i, j) = (i == j) ? colbuf[j] : colbuf[i] * inv; }
         SYNC;
     }
 }
-__device__ void small_ldl_solve(SmallQP &P, const double *b, double *x) {
+// x lives in LDS (xs) for the duration of the solve
+__device__ void small_ldl_solve(SmallQP &P, const KView &kv, const double *b, double *xout, double *xs) {
     const int n = P.n;
-    const double *K = P.K;
-    FOR_T(i, n) x[i] = b[i];
+    FOR_T(i, n) xs[i] = b[i];
     SYNC;
-    for (int j = 0; j < n; j++) {                 // L z = b
-        const double xj = x[j];
-        const double *cj = K + (size_t)j * n;
-        SYNC;
-        FOR_T(ii, n - j - 1) { const int i = j + 1 + ii; x[i] -= cj[i] * xj; }
+    for (int j = 0; j < n; j++) {                 // L z = b  (x_j is final when the loop reaches it)
+        const double xj = xs[j];
+        FOR_T(ii, n - j - 1) { const int i = j + 1 + ii; xs[i] -= kv.at(i, j) * xj; }
         SYNC;
     }
-    FOR_T(j, n) x[j] /= K[j + (size_t)j * n];
+    FOR_T(j, n) xs[j] /= kv.at(j, j);
     SYNC;
     for (int j = n - 1; j >= 0; j--) {            // L' x = z, column oriented: x_j is final, eliminate it from the rows above
-        const double xj = x[j];
-        SYNC;
-        FOR_T(i, j) x[i] -= K[j + (size_t)i * n] * xj;
+        const double xj = xs[j];
+        FOR_T(i, j) xs[i] -= kv.at(j, i) * xj;
         SYNC;
     }
+    FOR_T(i, n) xout[i] = xs[i];
+    SYNC;
 }
 
 // ---- linesearch (linesearch.c:8-158) -------------------------------------------------------------------
-__device__ double small_linesearch(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, double *tm, double *sm, u64 *skey, u32 *sidx) {
+__device__ double small_linesearch(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, unsigned char *jflag, double *tm, double *sm, u64 *skey, u32 *sidx) {
     const int n = P.n, m = P.m;
     double *dy = V[MV_DY], *mu = V[MV_MU], *isq = V[MV_ISQ], *w = V[MV_W], *y = V[MV_Y], *Adx = V[MV_ADX];
     FOR_T(i, m) { double s = dy[i] * mu[i]; s = s * 0.5; tm[i] = s; }
@@ -260,20 +261,17 @@ __device__ double small_linesearch(SmallQP &P, double *V[], double *ls_delta, do
             }
             SYNC;
         }
-    // J sums and the walk, sequentially on one lane (linesearch.c:108-157)
+    // L / P / J flags in parallel; the J sums and the walk sequentially on one lane (linesearch.c:108-157)
+    FOR_T(i, M2) {
+        const double dl = ls_delta[i], t = ls_alpha[i] / dl;
+        const int L = t > 0, Pp = dl > 0;
+        jflag[i] = (unsigned char)(L | (((Pp + L) == 1) << 1));
+    }
+    SYNC;
     if (threadIdx.x == 0) {
         double sa = 0.0, sb = 0.0; int nL = 0;
-        for (int i = 0; i < M2; i++) {
-            const double dl = ls_delta[i], t = ls_alpha[i] / dl;
-            const int L = t > 0, Pp = dl > 0;
-            nL += L;
-            if ((Pp + L) == 1) sa += dl * dl;
-        }
-        for (int i = 0; i < M2; i++) {
-            const double dl = ls_delta[i], al = ls_alpha[i], t = al / dl;
-            const int L = t > 0, Pp = dl > 0;
-            if ((Pp + L) == 1) sb += dl * al;
-        }
+        for (int i = 0; i < M2; i++) { nL += jflag[i] & 1; if (jflag[i] & 2) { const double dl = ls_delta[i]; sa += dl * dl; } }
+        for (int i = 0; i < M2; i++) if (jflag[i] & 2) sb += ls_delta[i] * ls_alpha[i];
         double a = eta + sa, b = beta - sb, tau;
         if (nL == 0) tau = -b / a;
         else {
@@ -320,11 +318,11 @@ __device__ void small_status(QPDOInfo &info, long st) {
 }
 
 // ---- the whole solve of one QP by one workgroup ----------------------------------------------------------
-__global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int count, QPDOSettings st) {
+__global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int count, QPDOSettings st, int klds_ok) {
     __shared__ double sm[32];
     __shared__ u64 skey[2 * SM_MAX_M];
     __shared__ u32 sidx[2 * SM_MAX_M];
-    extern __shared__ __attribute__((aligned(16))) double accbuf[];   // (threads/64) * max n doubles
+    extern __shared__ __attribute__((aligned(16))) double dyn[];      // [xs: n][colbuf: n][tk: n][ls_delta: 2m][ls_alpha: 2m][jflag: 2m bytes][K packed, if it fits]
     if ((int)blockIdx.x >= count) return;
     SmallQP &P = probs[blockIdx.x];
     const int n = P.n, m = P.m;
@@ -338,7 +336,10 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
            *res_prim_old = V[MV_RPOLD], *res_prim_in = V[MV_RPI], *dy = V[MV_DY], *Adx = V[MV_ADX], *dw = V[MV_DW], *E = V[MV_E],
            *Einv = V[MV_EINV], *ats = V[MV_ATS], *tm = V[MV_T];
     int *active = P.iv, *active_old = P.iv + m, *changed = P.iv + 2 * m;
-    double *ls_delta = P.lsv, *ls_alpha = P.lsv + 2 * (size_t)m;
+    double *xs = dyn, *colbuf = dyn + n, *tk = dyn + 2 * (size_t)n, *ls_delta = dyn + 3 * (size_t)n, *ls_alpha = ls_delta + 2 * (size_t)m;
+    unsigned char *jflag = (unsigned char *)(ls_alpha + 2 * (size_t)m);
+    double *Klds = (double *)(jflag + (((size_t)2 * m + 15) & ~(size_t)15));
+    KView kv; kv.n = n; kv.packed = klds_ok; kv.K = klds_ok ? Klds : P.K;
     const int scaled = st.scaling > 0, prox = (int)st.proximal;
     double sc_c = 1.0, sc_cinv = 1.0;
 
@@ -545,9 +546,9 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
             SYNC;
             FOR_T(j, n) rhs[j] = -res_dual_in[j] - Atdy[j];
             SYNC;
-            if (!factor_valid) { small_assemble(P, dw, sigma_f, accbuf); small_factor(P, tn); factor_valid = 1; nfactor++; }
+            if (!factor_valid) { small_assemble(P, kv, dw, sigma_f); small_factor(P, kv, colbuf, tk); factor_valid = 1; nfactor++; }
             last_branch = branch; last_sigma_f = sigma_f;
-            small_ldl_solve(P, rhs, dx);
+            small_ldl_solve(P, kv, rhs, dx, xs);
             spmv_rows(n, P.Qrp, P.Qci, P.Qval, dx, Qdx);
             spmv_rows(m, P.Arp, P.Aci, P.Aval, dx, Adx);
             SYNC;
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
             SYNC;
             spmv_rows(n, P.Trp, P.Tci, P.Tval, dy, Atdy);
             SYNC;
-            tau = small_linesearch(P, V, ls_delta, ls_alpha, tm, sm, skey, sidx);
+            tau = small_linesearch(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx);
             FOR_T(j, n) { x[j] = x[j] + tau * dx[j]; Qx[j] = Qx[j] + tau * Qdx[j]; Aty[j] = Aty[j] + tau * Atdy[j]; }
             FOR_T(i, m) { y[i] = y[i] + tau * dy[i]; Ax[i] = Ax[i] + tau * Adx[i]; }
             SYNC;
@@ -718,11 +719,15 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
     }
     SHIP(hipMemcpyAsync(dprobs, hp.data(), (size_t)count * sizeof(SmallQP), hipMemcpyHostToDevice, stream));
     {
-        size_t nmax = 1;
-        for (long i = 0; i < count; i++) if (items[i].data->n > nmax) nmax = items[i].data->n;
-        const size_t lds = (SM_THREADS / 64) * nmax * sizeof(double);
-        SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        hipLaunchKernelGGL(k_small_solve, dim3((unsigned)count), dim3(SM_THREADS), lds, stream, dprobs, (int)count, *settings);
+        size_t nmax = 1, mmax = 0;
+        for (long i = 0; i < count; i++) { if (items[i].data->n > nmax) nmax = items[i].data->n; if (items[i].data->m > mmax) mmax = items[i].data->m; }
+        size_t lds = 3 * nmax * 8 + 4 * mmax * 8 + ((2 * mmax + 15) & ~(size_t)15);
+        const size_t kbytes = nmax * (nmax + 1) / 2 * 8;
+        const size_t budget = 160 * 1024 - 26 * 1024;          // static LDS: sort keys + indices + scratch
+        const int klds_ok = (lds + kbytes <= budget) ? 1 : 0;
+        if (klds_ok) lds += kbytes;
+        SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(budget)));
+        hipLaunchKernelGGL(k_small_solve, dim3((unsigned)count), dim3(SM_THREADS), lds, stream, dprobs, (int)count, *settings, klds_ok);
     }
     SHIP(hipGetLastError());
     SHIP(hipMemcpyAsync(hp.data(), dprobs, (size_t)count * sizeof(SmallQP), hipMemcpyDeviceToHost, stream));
