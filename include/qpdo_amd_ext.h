@@ -67,6 +67,18 @@ int  qpdo_amd_linesearch(QPDOWorkspace *work, double eta, double beta, const dou
  * 5 dx, 6 dy, 7 Ax, 8 Aty, 9 l, 10 u */
 int  qpdo_amd_download(QPDOWorkspace *work, int which, double *dst);
 
+/* ---- one large QP row-partitioned over G GPUs (BASELINE.json configs[3]) --------------------------------
+ * One process per GPU.  Every rank calls the normal API with the SAME full problem; the library keeps rows
+ * [rank*ceil(m/G), ...) of A (and the matching slices of A' and, for the PCG operator, of Q) on its GPU and
+ * replicates the vectors.  The exchange step is one sum all-reduce of an n-vector per A' / K product: RCCL on
+ * the solver's stream (rccl_unique_id: 128 bytes created by rank 0 with qpdo_amd_dist_unique_id and sent to
+ * the others by the caller), or - for tests on a single GPU - a host callback `fn` (e.g. gloo).
+ * Applies to workspaces set up afterwards in this process; world = 1 switches it off.  All ranks obtain the
+ * same status, counts and solution. */
+typedef void (*qpdo_amd_allreduce_fn)(void *ctx, double *buf, long count, int op /* 0 sum, 1 max */);
+int  qpdo_amd_dist_config(int rank, int world, const void *rccl_unique_id, qpdo_amd_allreduce_fn fn, void *ctx);
+int  qpdo_amd_dist_unique_id(void *out128);
+
 /* ---- batch of independent QPs (BASELINE.json configs[2]: MPC-sized problems, no collective) --------------
  * Every item is set up, (optionally warm started,) solved and cleaned up through the same entry points as above,
  * by `nthreads` host threads, each with its own workspace and HIP stream on the device of this process

@@ -72,7 +72,7 @@ def build_lib(force=False, verbose=False):
         subprocess.check_call(["gcc", "-std=gnu11", "-ffp-contract=off", "-Wall", *common,
                                "-c", os.path.join(CSRC, s), "-o", o])
         objs.append(o)
-    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-lm", "-lpthread"])
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-lm", "-lpthread", "-L/opt/rocm/lib", "-lrccl"])
     return LIB_PATH
 
 

@@ -263,6 +263,18 @@ static c_float *vec_dup(const c_float *a, size_t n) {
     return b;
 }
 
+/* distributed configuration for the workspaces created next in this process */
+static QdevDist g_dist = {0, 1, 0, 0, 0, 0, NULL, NULL, {0}};
+int qpdo_amd_dist_config(int rank, int world, const void *rccl_unique_id, qpdo_amd_allreduce_fn fn, void *ctx) {
+    if (world < 1 || rank < 0 || rank >= world) return -1;
+    memset(&g_dist, 0, sizeof(g_dist));
+    g_dist.rank = rank; g_dist.world = world; g_dist.fn = (qdev_allreduce_fn)fn; g_dist.ctx = ctx;
+    if (rccl_unique_id) memcpy(g_dist.nccl_id, rccl_unique_id, 128);
+    if (world > 1 && !fn && !rccl_unique_id) return -1;
+    return 0;
+}
+int qpdo_amd_dist_unique_id(void *out128) { return qdev_rccl_unique_id(out128); }
+
 static int env_int(const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
 static double env_double(const char *name, double dflt) { const char *v = getenv(name); return (v && *v) ? atof(v) : dflt; }
 
@@ -345,7 +357,41 @@ QPDOWorkspace *qpdo_setup(const QPDOData *data, const QPDOSettings *settings) {
             QPDO_EPRINT("no HIP device available (this library has no CPU path)"); goto fail;
         }
         device = device % ndev;
-        int rc = qdev_create(&work->chol->dev, device, (int32_t)n, (int32_t)m, &a, &t, &qf, work->data->q, work->data->l, work->data->u);
+        int rc;
+        if (g_dist.world <= 1) {
+            rc = qdev_create(&work->chol->dev, device, (int32_t)n, (int32_t)m, &a, &t, &qf, work->data->q, work->data->l, work->data->u);
+        } else {
+            /* row partition: rows [m0, m0+mloc) of A, the same columns of A', rows [n0, n0+nloc) of Q */
+            QdevDist dd = g_dist;
+            const int64_t rpm = ((int64_t)m + dd.world - 1) / dd.world, rpn = ((int64_t)n + dd.world - 1) / dd.world;
+            int64_t m0 = (int64_t)dd.rank * rpm; if (m0 > (int64_t)m) m0 = (int64_t)m;
+            int64_t m1 = m0 + rpm; if (m1 > (int64_t)m) m1 = (int64_t)m;
+            int64_t n0 = (int64_t)dd.rank * rpn; if (n0 > (int64_t)n) n0 = (int64_t)n;
+            int64_t n1 = n0 + rpn; if (n1 > (int64_t)n) n1 = (int64_t)n;
+            dd.m0 = (int32_t)m0; dd.mloc = (int32_t)(m1 - m0); dd.n0 = (int32_t)n0; dd.nloc = (int32_t)(n1 - n0);
+            int32_t *arp = malloc(((size_t)dd.mloc + 1) * sizeof(int32_t)), *qrp = malloc(((size_t)dd.nloc + 1) * sizeof(int32_t));
+            int32_t *trp = malloc(((size_t)n + 1) * sizeof(int32_t));
+            int64_t tn = 0;
+            for (int64_t j = 0; j < (int64_t)n; j++) for (int32_t k = At.rp[j]; k < At.rp[j + 1]; k++) tn += (At.ci[k] >= m0 && At.ci[k] < m1);
+            int32_t *tci = malloc((size_t)(tn ? tn : 1) * sizeof(int32_t)); double *tval = malloc((size_t)(tn ? tn : 1) * sizeof(double));
+            if (!arp || !qrp || !trp || !tci || !tval) { free(arp); free(qrp); free(trp); free(tci); free(tval); rc = -1; }
+            else {
+                for (int32_t i = 0; i <= dd.mloc; i++) arp[i] = Ar.rp[m0 + i] - Ar.rp[m0];
+                for (int32_t i = 0; i <= dd.nloc; i++) qrp[i] = Qf.rp[n0 + i] - Qf.rp[n0];
+                int64_t pos = 0;
+                for (int64_t j = 0; j < (int64_t)n; j++) {
+                    trp[j] = (int32_t)pos;
+                    for (int32_t k = At.rp[j]; k < At.rp[j + 1]; k++)
+                        if (At.ci[k] >= m0 && At.ci[k] < m1) { tci[pos] = At.ci[k] - (int32_t)m0; tval[pos] = At.val[k]; pos++; }
+                }
+                trp[n] = (int32_t)pos;
+                QdevCsr al = {dd.mloc, (int32_t)n, arp[dd.mloc], arp, Ar.ci + Ar.rp[m0], Ar.val + Ar.rp[m0]};
+                QdevCsr tl = {(int32_t)n, dd.mloc, pos, trp, tci, tval};
+                QdevCsr ql = {dd.nloc, (int32_t)n, qrp[dd.nloc], qrp, Qf.ci + Qf.rp[n0], Qf.val + Qf.rp[n0]};
+                rc = qdev_create_dist(&work->chol->dev, device, (int32_t)n, (int32_t)m, &al, &tl, &qf, &ql, work->data->q, work->data->l, work->data->u, &dd);
+                free(arp); free(qrp); free(trp); free(tci); free(tval);
+            }
+        }
         host_csr_free(&Ar); host_csr_free(&At); host_csr_free(&Qf);
         if (rc) { QPDO_EPRINT("device backend: %s", qdev_last_error()); goto fail; }
         const char *ls = getenv("QPDO_LINSOLVE");

@@ -51,6 +51,20 @@ const char *qdev_last_error(void);
 int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m,
                 const QdevCsr *Ar, const QdevCsr *At, const QdevCsr *Qf,
                 const double *q, const double *l, const double *u);
+/* row partition of one large QP (one process per GPU).  fn != NULL: host-callback all-reduce (tests);
+ * fn == NULL and world > 1: RCCL with the 128-byte unique id of rank 0. */
+typedef void (*qdev_allreduce_fn)(void *ctx, double *buf, long count, int op /*0 sum, 1 max*/);
+typedef struct {
+    int rank, world;
+    int32_t m0, mloc;        /* rows of A held by this rank                      */
+    int32_t n0, nloc;        /* rows of Q applied by this rank inside PCG        */
+    qdev_allreduce_fn fn; void *ctx;
+    unsigned char nccl_id[128];
+} QdevDist;
+/* Ar: local rows (mloc x n); At: local columns (n x mloc, column indices local); Qf: full Q; Qs: rows [n0, n0+nloc) of Q */
+int qdev_create_dist(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *Ar, const QdevCsr *At, const QdevCsr *Qf,
+                     const QdevCsr *Qs, const double *q, const double *l, const double *u, const QdevDist *dist);
+int qdev_rccl_unique_id(void *out128);
 void qdev_destroy(QpdoDev *d);
 int qdev_sync(QpdoDev *d);
 

@@ -19,6 +19,8 @@
 #include <cstring>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "qpdo_dev.h"
 
 typedef unsigned long long u64;
@@ -69,10 +71,24 @@ struct DevCsr {
     double alg_bytes() const { return 12.0 * (double)nnz + 4.0 * (nrows + 1) + 8.0 * nrows + 8.0 * ncols; }
 };
 
+// Row partition of one large QP over G ranks (one process per GPU): every vector is replicated, only the
+// matrices are split (rows [m0, m0+mloc) of A, the matching columns of A', rows [n0, n0+nloc) of Q for the PCG
+// operator).  The single exchange step is a sum all-reduce of an n-vector per A' / K product (plus max / sum
+// all-reduces of the Ruiz norms and of A x results): RCCL on the backend stream, or a host callback (tests).
+struct Comm {
+    int rank = 0, world = 1, mode = 0;          // mode: 0 none, 1 host callback, 2 RCCL
+    qdev_allreduce_fn fn = nullptr; void *ctx = nullptr;
+    ncclComm_t nccl = nullptr;
+    double *hbuf = nullptr; size_t hcap = 0;     // pinned staging for the host-callback mode
+};
 struct QpdoDev {
     int device = 0, n = 0, m = 0;
+    int m0 = 0, mloc = 0, n0 = 0, nloc = 0;      // this rank's slices (whole ranges when world == 1)
+    Comm comm;
+    double *dist_tmp = nullptr, *Kp_part = nullptr, *zeros_n = nullptr;
     hipStream_t stream = nullptr;
-    DevCsr Ar, At, Qf;
+    DevCsr Ar, At, Qf;        // world > 1: Ar = local rows (mloc x n), At = local columns (n x mloc), Qf replicated
+    DevCsr Qs;                // world > 1: rows [n0, n0+nloc) of Qf for the PCG operator
     // compact index space of the current Newton pass: the k weighted rows of A, renumbered 0..k-1
     DevCsr Arc, Atc;          // A_c (k x n) and A_c' (n x k)
     int *row_cnt = nullptr, *cidx = nullptr, *rowlist = nullptr, *kcount = nullptr; int kact = 0;
@@ -552,6 +568,13 @@ __global__ __launch_bounds__(256) void k_scale_sym(int nrows, const int *__restr
             const double t = row >= c ? D[c] * D[row] : D[row] * D[c];
             val[k] *= t;
         }
+    }
+}
+__global__ void k_scale_sym_rows(int nrows, int row0, const int *__restrict__ rp, const int *__restrict__ ci, double *__restrict__ val,
+                                 const double *__restrict__ D) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+        const int row = r + row0;
+        for (int k = rp[r]; k < rp[r + 1]; k++) { const int c = ci[k]; val[k] *= (row >= c ? D[c] * D[row] : D[row] * D[c]); }
     }
 }
 __global__ void k_scale_vals(long long nnz, double *__restrict__ val, double f) {
@@ -1729,17 +1752,102 @@ static inline double nrm_of(const Ctrl *c, int slot) {
 }
 #define LAUNCH(kernel, grid, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLK), 0, d->stream, __VA_ARGS__)
 
+// ---- collectives ----------------------------------------------------------------------------------------
+static int comm_allreduce(QpdoDev *d, double *dev, size_t cnt, int op /*0 sum, 1 max*/) {
+    Comm &c = d->comm;
+    if (c.world <= 1 || cnt == 0) return 0;
+    if (c.mode == 2) {
+        ncclResult_t r = ncclAllReduce(dev, dev, cnt, ncclDouble, op ? ncclMax : ncclSum, c.nccl, d->stream);
+        if (r != ncclSuccess) { snprintf(g_err, sizeof(g_err), "ncclAllReduce: %s", ncclGetErrorString(r)); return -1; }
+        return 0;
+    }
+    if (c.mode == 1) {
+        if (cnt > c.hcap) { snprintf(g_err, sizeof(g_err), "allreduce staging too small"); return -1; }
+        HIPCHK(hipMemcpyAsync(c.hbuf, dev, cnt * 8, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        c.fn(c.ctx, c.hbuf, (long)cnt, op);
+        HIPCHK(hipMemcpyAsync(dev, c.hbuf, cnt * 8, hipMemcpyHostToDevice, d->stream));
+        return 0;
+    }
+    snprintf(g_err, sizeof(g_err), "distributed workspace without a communicator");
+    return -1;
+}
+// row epilogue applied after the exchange: the same functors the fused single-GPU products use
+template <class Epi>
+__global__ __launch_bounds__(256) void k_epi_apply(int nrows, const double *__restrict__ sums, Epi epi) {
+    __shared__ double sm[32];
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) epi.row(r, sums[r]);
+    epi.finish(sm);
+}
+// y = A x with epilogue (global row space m); world > 1: local rows, sum all-reduce, then the epilogue
+template <class Epi>
+static int spmv_A(QpdoDev *d, const double *x, Epi epi, bool partials) {
+    if (d->comm.world <= 1) { launch_spmv(d, d->Ar, x, epi, partials); return 0; }
+    HIPCHK(hipMemsetAsync(d->dist_tmp, 0, (size_t)d->m * 8, d->stream));
+    launch_spmv(d, d->Ar, x, EpiStore{d->dist_tmp + d->m0}, false);
+    int rc = comm_allreduce(d, d->dist_tmp, (size_t)d->m, 0); if (rc) return rc;
+    hipLaunchKernelGGL((k_epi_apply<Epi>), dim3(vgrid(d->m)), dim3(BLK), 0, d->stream, d->m, (const double *)d->dist_tmp, epi);
+    return 0;
+}
+static inline int pgrid_A(QpdoDev *d) { return d->comm.world <= 1 ? spmv_pgrid(d->Ar) : vgrid(d->m); }
+// y = A' x with epilogue (x is a global m-vector); world > 1: local columns, sum all-reduce, then the epilogue
+template <class Epi>
+static int spmv_At(QpdoDev *d, const double *x, Epi epi, bool partials) {
+    if (d->comm.world <= 1) { launch_spmv(d, d->At, x, epi, partials); return 0; }
+    launch_spmv(d, d->At, x + d->m0, EpiStore{d->dist_tmp}, false);
+    int rc = comm_allreduce(d, d->dist_tmp, (size_t)d->n, 0); if (rc) return rc;
+    hipLaunchKernelGGL((k_epi_apply<Epi>), dim3(vgrid(d->n)), dim3(BLK), 0, d->stream, d->n, (const double *)d->dist_tmp, epi);
+    return 0;
+}
+// PCG pieces of the distributed operator
+__global__ void k_pcg_dist_finish(int n, const int *__restrict__ done, const double *__restrict__ part, const double *__restrict__ p,
+                                  double sigma_f, double *__restrict__ Kp, double *__restrict__ p_pKp) {
+    __shared__ double sm[32];
+    if (*done) return;
+    double acc = 0.0;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const double v = part[j] + sigma_f * p[j];
+        Kp[j] = v; acc += p[j] * v;
+    }
+    double t = block_sum(acc, sm);
+    if (threadIdx.x == 0) p_pKp[blockIdx.x] = t;
+}
+struct EpiAddTo {                          // out[r + off] += s   (partial operator rows)
+    double *out; int off;
+    __device__ bool skip(int) const { return false; }
+    __device__ void row(int r, double s) { out[r + off] += s; }
+    __device__ void finish(double *) {}
+};
+__global__ void k_add3(int n, const double *__restrict__ a, const double *__restrict__ b, double c, double *__restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = a[i] + b[i] + c;
+}
+
 extern "C" {
 
+int qdev_rccl_unique_id(void *out128) {
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return -1;
+    memcpy(out128, &id, sizeof(id) < 128 ? sizeof(id) : 128);
+    return 0;
+}
 int qdev_device_count(void) { int c = 0; if (hipGetDeviceCount(&c) != hipSuccess) return 0; return c; }
 const char *qdev_last_error(void) { return g_err; }
 
 int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *Ar, const QdevCsr *At, const QdevCsr *Qf,
                 const double *q, const double *l, const double *u) {
+    QdevDist none; memset(&none, 0, sizeof(none));
+    none.world = 1; none.mloc = m; none.nloc = n;
+    return qdev_create_dist(out, device, n, m, Ar, At, Qf, (const QdevCsr *)nullptr, q, l, u, &none);
+}
+int qdev_create_dist(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *Ar, const QdevCsr *At, const QdevCsr *Qf,
+                     const QdevCsr *Qs, const double *q, const double *l, const double *u, const QdevDist *dist) {
     *out = nullptr;
     HIPCHK(hipSetDevice(device));
     QpdoDev *d = new QpdoDev();
     d->device = device; d->n = n; d->m = m;
+    d->m0 = dist->m0; d->mloc = dist->mloc; d->n0 = dist->n0; d->nloc = dist->nloc;
+    d->comm.rank = dist->rank; d->comm.world = dist->world; d->comm.fn = dist->fn; d->comm.ctx = dist->ctx;
+    d->comm.mode = dist->world > 1 ? (dist->fn ? 1 : 2) : 0;
     int rc = 0;
     hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete d; return set_err(e, "hipStreamCreate", __LINE__); }
@@ -1747,6 +1855,7 @@ int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *
     if (!rc) rc = upload_csr(d, &d->Ar, Ar);
     if (!rc) rc = upload_csr(d, &d->At, At);
     if (!rc) rc = upload_csr(d, &d->Qf, Qf);
+    if (!rc && Qs && dist->world > 1) rc = upload_csr(d, &d->Qs, Qs);
     A_(x, n); A_(xbar, n); A_(Qx, n); A_(Aty, n); A_(q, n); A_(df, n); A_(res_dual, n); A_(res_dual_in, n); A_(rhs, n);
     A_(dx, n); A_(Qdx, n); A_(Atdy, n); A_(D, n); A_(Dinv, n);
     A_(pc_r, n); A_(pc_z, n); A_(pc_p, n); A_(pc_Kp, n); A_(pc_diag, n); A_(tmp_n, n);
@@ -1775,6 +1884,19 @@ int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *
     if (!rc) rc = setup_slabs(d, &d->Ar);
     if (!rc) rc = setup_slabs(d, &d->At);
     if (!rc) rc = setup_slabs(d, &d->Qf);
+    if (!rc && d->comm.world > 1 && d->Qs.nrows > 0) rc = setup_slabs(d, &d->Qs);
+    if (!rc && d->comm.world > 1) {
+        const size_t mx = (size_t)(n > m ? n : m);
+        rc = dev_alloc(d, &d->dist_tmp, mx);
+        if (!rc) rc = dev_alloc(d, &d->Kp_part, (size_t)n);
+        if (!rc) rc = dev_alloc(d, &d->zeros_n, (size_t)n);
+        if (!rc && d->comm.mode == 1) { hipError_t e2 = hipHostMalloc((void **)&d->comm.hbuf, mx * 8, hipHostMallocDefault); if (e2 != hipSuccess) rc = set_err(e2, "hipHostMalloc", __LINE__); else d->comm.hcap = mx; }
+        if (!rc && d->comm.mode == 2) {
+            ncclUniqueId id; memcpy(&id, dist->nccl_id, sizeof(id));
+            ncclResult_t r = ncclCommInitRank(&d->comm.nccl, dist->world, id, dist->rank);
+            if (r != ncclSuccess) { snprintf(g_err, sizeof(g_err), "ncclCommInitRank: %s", ncclGetErrorString(r)); rc = -1; }
+        }
+    }
     if (!rc) {   // per-pass compact copies used by PCG
         d->Arc = d->Ar; d->Arc.rp = nullptr; d->Arc.ci = nullptr; d->Arc.val = nullptr; d->Arc.sp = nullptr; d->Arc.ci16 = nullptr;
         d->Atc = d->At; d->Atc.rp = nullptr; d->Atc.ci = nullptr; d->Atc.val = nullptr; d->Atc.sp = nullptr; d->Atc.ci16 = nullptr;
@@ -1799,7 +1921,7 @@ int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *
         const char *df = getenv("QPDO_DEFLATE");
         d->deflate = !(df && !strcmp(df, "0"));
         int mx = 0;
-        for (int i = 0; i < m; i++) { const int len = Ar->rp[i + 1] - Ar->rp[i]; if (len > mx) mx = len; }
+        for (int i = 0; i < Ar->nrows; i++) { const int len = Ar->rp[i + 1] - Ar->rp[i]; if (len > mx) mx = len; }
         d->max_row_nnz_A = mx;
         if (d->deflate && m > 0) {
             d->Ath = DevCsr(); d->Ath.nrows = n; d->Ath.ncols = m;
@@ -1828,6 +1950,8 @@ void qdev_destroy(QpdoDev *d) {
     if (d->stream) hipStreamSynchronize(d->stream);
     for (void *p : d->allocs) hipFree(p);
     if (d->hctrl) hipHostFree(d->hctrl);
+    if (d->comm.hbuf) hipHostFree(d->comm.hbuf);
+    if (d->comm.nccl) ncclCommDestroy(d->comm.nccl);
     if (d->ev0) hipEventDestroy(d->ev0);
     if (d->ev1) hipEventDestroy(d->ev1);
     if (d->stream) hipStreamDestroy(d->stream);
@@ -1842,6 +1966,7 @@ int qdev_configure(QpdoDev *d, int linsolve, double pcg_tol, int pcg_maxit) {
     if (linsolve >= 0) d->linsolve = linsolve;
     else d->linsolve = (d->n <= d->dense_max_n) ? 1 : 0;
     if (d->linsolve == 1 && d->n > 18000) d->linsolve = 0;
+    if (d->comm.world > 1) { d->linsolve = 0; d->deflate = 0; }   // the dense factor and the Woodbury rows are not partitioned
     if (pcg_tol > 0) d->pcg_tol = pcg_tol;
     if (pcg_maxit > 0) d->pcg_maxit = pcg_maxit;
     d->st.linsolve = d->linsolve;
@@ -1865,17 +1990,23 @@ int qdev_scale_data(QpdoDev *d, int iters, int use_Qx, double *D_host, double *E
     for (int it = 0; it < iters; it++) {
         // column norms of A = row norms of CSR(A'); row norms of A = row norms of CSR(A)
         DISPATCH_TPR(d->At, k_row_absmax, gAt, n, d->At.rp, d->At.val, d->tmp_n);
-        DISPATCH_TPR(d->Ar, k_row_absmax, gAr, m, d->Ar.rp, d->Ar.val, d->tmp_m);
+        if (d->comm.world > 1) {   // max over the row slices; row norms gathered through a sum with zero padding
+            int rcx = comm_allreduce(d, d->tmp_n, (size_t)n, 1); if (rcx) return rcx;
+            HIPCHK(hipMemsetAsync(d->tmp_m, 0, (size_t)m * 8, d->stream));
+        }
+        DISPATCH_TPR(d->Ar, k_row_absmax, gAr, d->mloc, d->Ar.rp, d->Ar.val, d->tmp_m + d->m0);
+        if (d->comm.world > 1) { int rcx = comm_allreduce(d, d->tmp_m, (size_t)m, 0); if (rcx) return rcx; }
         LAUNCH(k_ruiz_factor, vgrid(n), n, d->tmp_n, d->D);
         LAUNCH(k_ruiz_factor, vgrid(m), m, d->tmp_m, d->E);
         // A <- E A D: (a * E_i) * D_j on both stored copies
-        DISPATCH_TPR(d->Ar, k_scale_rows_cols, gAr, m, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)d->tmp_m, (const double *)nullptr,
+        DISPATCH_TPR(d->Ar, k_scale_rows_cols, gAr, d->mloc, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)(d->tmp_m + d->m0), (const double *)nullptr,
                      (const double *)nullptr, (const double *)d->tmp_n);
-        DISPATCH_TPR(d->At, k_scale_rows_cols, gAt, n, d->At.rp, d->At.ci, d->At.val, (const double *)nullptr, (const double *)d->tmp_m,
+        DISPATCH_TPR(d->At, k_scale_rows_cols, gAt, n, d->At.rp, d->At.ci, d->At.val, (const double *)nullptr, (const double *)(d->tmp_m + d->m0),
                      (const double *)d->tmp_n, (const double *)nullptr);
     }
     const int gQ = spmv_grid(d->Qf, d->Qf.tpr, false);
     DISPATCH_TPR(d->Qf, k_scale_sym, gQ, n, d->Qf.rp, d->Qf.ci, d->Qf.val, (const double *)d->D);
+    if (d->comm.world > 1 && d->Qs.nnz) hipLaunchKernelGGL(k_scale_sym_rows, dim3(vgrid(d->nloc)), dim3(BLK), 0, d->stream, d->nloc, d->n0, d->Qs.rp, d->Qs.ci, d->Qs.val, (const double *)d->D);
     d->qdiag_valid = 0; d->dense_valid = 0;
     LAUNCH(k_mul, vgrid(n), n, d->D, d->q, d->q);                    // q <- D q
     // cost scaling: c = 1 / max(1, ||Qx + q||inf)
@@ -1887,6 +2018,7 @@ int qdev_scale_data(QpdoDev *d, int iters, int use_Qx, double *D_host, double *E
     // q <- c q (vec_self_mult_scalar), Q <- c Q
     LAUNCH(k_scal, vgrid(n), n, c, d->q);
     if (d->Qf.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qf.nnz, d->Qf.val, c);
+    if (d->comm.world > 1 && d->Qs.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qs.nnz, d->Qs.val, c);
     HIPCHK(hipMemcpyAsync(D_host, d->D, (size_t)n * 8, hipMemcpyDeviceToHost, d->stream));
     if (m) HIPCHK(hipMemcpyAsync(E_host, d->E, (size_t)m * 8, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
@@ -1931,6 +2063,7 @@ int qdev_download_q(QpdoDev *d, double *q) {
 int qdev_scale_Q_values(QpdoDev *d, double factor) {
     HIPCHK(hipSetDevice(d->device));
     d->qdiag_valid = 0; d->dense_valid = 0;
+    if (d->comm.world > 1 && d->Qs.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qs.nnz, d->Qs.val, factor);
     if (d->Qf.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qf.nnz, d->Qf.val, factor);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1991,7 +2124,7 @@ int qdev_warm_start(QpdoDev *d, const double *x_ws, const double *y_ws, int prox
         HIPCHK(hipMemcpyAsync(d->tmp_n, x_ws, (size_t)n * 8, hipMemcpyHostToDevice, d->stream));
         LAUNCH(k_ws_x, vgrid(n), n, d->scaled, d->tmp_n, d->Dinv, d->x, d->xbar);
         launch_spmv(d, d->Qf, d->x, EpiQpure{d->x, sigma, proximal, d->Qx}, false);
-        launch_spmv(d, d->Ar, d->x, EpiStore{d->Ax}, false);
+        { int rc2 = spmv_A(d, d->x, EpiStore{d->Ax}, false); if (rc2) return rc2; }
         int rc = qdev_objective(d, proximal, sigma, c_const, objective); if (rc) return rc;
     } else {
         HIPCHK(hipMemsetAsync(d->x, 0, (size_t)n * 8, d->stream));
@@ -2002,7 +2135,7 @@ int qdev_warm_start(QpdoDev *d, const double *x_ws, const double *y_ws, int prox
     if (y_ws && m) {
         HIPCHK(hipMemcpyAsync(d->tmp_m, y_ws, (size_t)m * 8, hipMemcpyHostToDevice, d->stream));
         LAUNCH(k_ws_y, vgrid(m), m, d->scaled, d->sc_c, d->tmp_m, d->Einv, d->y, d->ybar);
-        launch_spmv(d, d->At, d->y, EpiStore{d->Aty}, false);
+        { int rc2 = spmv_At(d, d->y, EpiStore{d->Aty}, false); if (rc2) return rc2; }
     } else {
         if (m) { HIPCHK(hipMemsetAsync(d->y, 0, (size_t)m * 8, d->stream)); HIPCHK(hipMemsetAsync(d->ybar, 0, (size_t)m * 8, d->stream)); }
         HIPCHK(hipMemsetAsync(d->Aty, 0, (size_t)n * 8, d->stream));
@@ -2043,16 +2176,17 @@ int qdev_residuals(QpdoDev *d, int proximal, double sigma, QdevResid *out) {
 // Build the compact index space of this Newton pass: k weighted rows, A_c (k x n) copied out of CSR(A),
 // A_c' (n x k) compacted out of CSR(A') with renumbered columns, d_c.  ~4 passes over A, once per Newton pass.
 static int build_compact(QpdoDev *d) {
-    const int n = d->n, m = d->m;
+    const int n = d->n, m = d->mloc;                 // local rows; dl = their weights
+    const double *dl = d->d + d->m0;
     d->kact = 0;
     if (m == 0) return 0;
-    hipLaunchKernelGGL(k_flag_scan, dim3(1), dim3(1024), 0, d->stream, m, (const double *)d->d, d->cidx, d->rowlist, d->kcount);
+    hipLaunchKernelGGL(k_flag_scan, dim3(1), dim3(1024), 0, d->stream, m, dl, d->cidx, d->rowlist, d->kcount);
     int k = 0;
     HIPCHK(hipMemcpyAsync(&k, d->kcount, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     if (k <= 0) return 0;
     // A_c: rows
-    LAUNCH(k_gather_rowinfo, vgrid(k), k, (const int *)d->rowlist, d->Ar.rp, (const double *)d->d, d->row_cnt, d->dc);
+    LAUNCH(k_gather_rowinfo, vgrid(k), k, (const int *)d->rowlist, d->Ar.rp, dl, d->row_cnt, d->dc);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d->stream, d->row_cnt, k, d->Arc.rp);
     LAUNCH(k_copy_rows, 2048, k, (const int *)d->rowlist, d->Ar.rp, d->Ar.ci, (const unsigned short *)d->Ar.ci16, d->Ar.val,
            (const int *)d->Arc.rp, d->Arc.ci, d->Arc.ci16, d->Arc.val);
@@ -2078,9 +2212,9 @@ static int build_compact(QpdoDev *d) {
         if (T.ci16 && W < 65536) W16 = W;
     }
     const int g = M.use_slab ? 2048 : spmv_grid(M, M.tpr, false);
-    DISPATCH_TPR(M, k_count_flagged, g, n, M.rp, M.ci, (const double *)d->d, d->row_cnt);
+    DISPATCH_TPR(M, k_count_flagged, g, n, M.rp, M.ci, dl, d->row_cnt);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d->stream, d->row_cnt, n, T.rp);
-    LAUNCH(k_compact_rows, 2048, n, M.rp, M.ci, M.val, (const double *)d->d, (const int *)T.rp, T.ci, T.val, (const int *)d->cidx, W16,
+    LAUNCH(k_compact_rows, 2048, n, M.rp, M.ci, M.val, dl, (const int *)T.rp, T.ci, T.val, (const int *)d->cidx, W16,
            M.ci16 ? d->Atc.ci16 : (unsigned short *)nullptr);
     DevCsr Tsave = T;     // (keep pointer to allocated ci16 even when this pass cannot use it)
     if (T.use_slab) LAUNCH(k_build_slab_ptr, vgrid(n), n, T.rp, T.ci, T.nslabs, T.W, T.sp, &d->kcount[1]);
@@ -2184,7 +2318,15 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
     const int k = d->kact;
     rc = defl_build(d); if (rc) return rc;
     const bool defl = d->defl_r > 0;
-    if (!defl) {   // Jacobi diagonal: Q_jj + sigma_f + sum_i A_ij^2 d_i
+    const bool dist = d->comm.world > 1;
+    if (!defl && dist) {   // sum_i A_ij^2 d_i over the local rows, summed over ranks, plus Q_jj + sigma_f
+        if (k > 0) {
+            const int gAt = d->At.use_slab ? 2048 : spmv_grid(d->At, d->At.tpr, false);
+            DISPATCH_TPR(d->At, k_jacobi_diag, gAt, n, d->Atc.rp, d->Atc.ci, d->Atc.val, (const double *)d->dc, (const double *)d->zeros_n, 0.0, d->dist_tmp);
+        } else HIPCHK(hipMemsetAsync(d->dist_tmp, 0, (size_t)n * 8, d->stream));
+        rc = comm_allreduce(d, d->dist_tmp, (size_t)n, 0); if (rc) return rc;
+        LAUNCH(k_add3, vgrid(n), n, (const double *)d->dist_tmp, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
+    } else if (!defl) {   // Jacobi diagonal: Q_jj + sigma_f + sum_i A_ij^2 d_i
         if (k > 0) {
             const int gAt = d->At.use_slab ? 2048 : spmv_grid(d->At, d->At.tpr, false);
             DISPATCH_TPR(d->At, k_jacobi_diag, gAt, n, d->Atc.rp, d->Atc.ci, d->Atc.val, (const double *)d->dc, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
@@ -2202,14 +2344,25 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
         LAUNCH(k_copy, g, n, (const double *)d->pc_z, d->pc_p);
     }
     LAUNCH(k_pcg_init2, 1, P + P_RZ * PGRID, cnt_rz, P + P_RR * PGRID, g, d->ctrl);
-    const int pKp_cnt = k > 0 ? spmv_pgrid(d->Atc) : spmv_pgrid(d->Qf);
+    const int pKp_cnt = dist ? vgrid(n) : (k > 0 ? spmv_pgrid(d->Atc) : spmv_pgrid(d->Qf));
     int it = 0;
     while (it < d->pcg_maxit) {
         const int it_before = it;
         int batch = d->pcg_batch; if (it + batch > d->pcg_maxit) batch = d->pcg_maxit - it;
         for (int b = 0; b < batch; b++) {
             const bool sample = (b == 0);
-            if (k > 0) {
+            if (dist) {
+                // K p = sigma_f p + sum over ranks of ( Q_rows p  [rows n0..]  +  A_c,loc' (d_c .* A_c,loc p) )
+                HIPCHK(hipMemsetAsync(d->Kp_part, 0, (size_t)n * 8, d->stream));
+                if (k > 0) launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
+                if (sample) hipEventRecord(d->ev0, d->stream);
+                if (d->nloc > 0) launch_spmv_pcg(d, d->Qs, d->pc_p, EpiAddTo{d->Kp_part, d->n0}, false);
+                if (sample) hipEventRecord(d->ev1, d->stream);
+                if (k > 0) launch_spmv_pcg(d, d->Atc, d->tc, EpiAddTo{d->Kp_part, 0}, false);
+                rc = comm_allreduce(d, d->Kp_part, (size_t)n, 0); if (rc) return rc;
+                hipLaunchKernelGGL(k_pcg_dist_finish, dim3(g), dim3(BLK), 0, d->stream, n, done, (const double *)d->Kp_part, (const double *)d->pc_p,
+                                   d->sigma_f, d->pc_Kp, P + P_PKP * PGRID);
+            } else if (k > 0) {
                 launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
                 if (sample) hipEventRecord(d->ev0, d->stream);
                 launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQ{d->pc_p, d->sigma_f, d->pc_Kp}, false);
@@ -2325,8 +2478,8 @@ int qdev_newton_step(QpdoDev *d, int branch, int n_changed, int proximal, double
     const int n = d->n, m = d->m;
     if (branch == 0 || branch == 2) d->sigma_f = proximal ? sigma : 0.0;     // ldlchol beta (cholmod_interface.c:11-13)
     LAUNCH(k_newton_prep, vgrid(m), m, branch, d->active, d->active_old, d->isq, d->mu, d->res_prim_in, d->d, d->dy);
-    launch_spmv(d, d->At, d->dy, EpiRhs{d->res_dual_in, d->Atdy, d->rhs}, false);
     int lin = 0, rc = 0;
+    rc = spmv_At(d, d->dy, EpiRhs{d->res_dual_in, d->Atdy, d->rhs}, false); if (rc) return rc;
     // the dense factor stays valid only while (sigma_f, d) is unchanged: full refactor (0) always rebuilds,
     // rank update (1) changes d iff rows entered or left, Q-only (2) is unchanged if the previous factor
     // was also Q-only at the same sigma
@@ -2350,9 +2503,9 @@ int qdev_newton_step(QpdoDev *d, int branch, int n_changed, int proximal, double
     e.Adx = d->Adx; e.dy = d->dy; e.delta = d->ls_delta; e.alpha = d->ls_alpha; e.key = d->ls_key[0]; e.idx = d->ls_idx[0];
     e.p_eta = d->part + P_ETA_M * PGRID; e.p_beta = d->part + P_BETA_M * PGRID; e.p_a0 = d->part + P_A0 * PGRID; e.p_b0 = d->part + P_B0 * PGRID;
     e.ctrl = d->ctrl;
-    launch_spmv(d, d->Ar, d->dx, e, true);
-    launch_spmv(d, d->At, d->dy, EpiStore{d->Atdy}, false);
-    rc = linesearch_device(d, spmv_pgrid(d->Ar), spmv_pgrid(d->Qf)); if (rc) return rc;
+    rc = spmv_A(d, d->dx, e, true); if (rc) return rc;
+    rc = spmv_At(d, d->dy, EpiStore{d->Atdy}, false); if (rc) return rc;
+    rc = linesearch_device(d, pgrid_A(d), spmv_pgrid(d->Qf)); if (rc) return rc;
     LAUNCH(k_axpy5, vgrid(n > m ? n : m), n, m, d->ctrl, d->x, d->dx, d->Qx, d->Qdx, d->Aty, d->Atdy, d->y, d->dy, d->Ax, d->Adx);
     rc = read_ctrl(d); if (rc) return rc;
     *tau_out = d->hctrl->val[V_TAU];
@@ -2366,7 +2519,7 @@ int qdev_primal_infeasibility(QpdoDev *d, double eps_prim_inf, int *is_infeasibl
     const int n = d->n, m = d->m;
     *is_infeasible = 0;
     LAUNCH(k_sub, vgrid(m), m, d->y, d->ybar, d->dy);                                  // qpdo.c:372
-    launch_spmv(d, d->At, d->dy, EpiStore{d->Atdy}, false);                            // qpdo.c:374
+    { int rc2 = spmv_At(d, d->dy, EpiStore{d->Atdy}, false); if (rc2) return rc2; }       // qpdo.c:374
     LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
     LAUNCH(k_absmax_mul, vgrid(m), m, (const double *)d->dy, d->scaled ? (const double *)d->E : (const double *)nullptr, d->ctrl, N_A);
     int rc = read_ctrl(d); if (rc) return rc;
@@ -2390,7 +2543,7 @@ int qdev_dual_infeasibility(QpdoDev *d, int proximal, double sigma, double tau, 
     *is_infeasible = 0;
     LAUNCH(k_sub, vgrid(n), n, d->x, d->xbar, d->dx);                                  // qpdo.c:383
     launch_spmv(d, d->Qf, d->dx, EpiStore{d->Qdx}, false);                             // qpdo.c:385 (no sigma)
-    launch_spmv(d, d->Ar, d->dx, EpiStore{d->Adx}, false);                             // qpdo.c:387
+    { int rc2 = spmv_A(d, d->dx, EpiStore{d->Adx}, false); if (rc2) return rc2; }        // qpdo.c:387
     LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
     LAUNCH(k_absmax_mul, vgrid(n), n, (const double *)d->dx, d->scaled ? (const double *)d->D : (const double *)nullptr, d->ctrl, N_C);
     int rc = read_ctrl(d); if (rc) return rc;

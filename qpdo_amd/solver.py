@@ -97,7 +97,7 @@ class BatchItem(C.Structure):
     _fields_ = [("data", C.POINTER(QPDOData)), ("x0", dp), ("y0", dp), ("x", dp), ("y", dp), ("info", QPDOInfo)]
 
 
-EXT_SYMBOLS = ["qpdo_amd_solve_batch", "qpdo_amd_device_count", "qpdo_amd_last_error", "qpdo_amd_get_stats", "qpdo_amd_get_trace",
+EXT_SYMBOLS = ["qpdo_amd_dist_config", "qpdo_amd_dist_unique_id", "qpdo_amd_solve_batch", "qpdo_amd_device_count", "qpdo_amd_last_error", "qpdo_amd_get_stats", "qpdo_amd_get_trace",
                "qpdo_amd_sync", "qpdo_amd_bench_spmv", "qpdo_amd_spmv", "qpdo_amd_linesearch", "qpdo_amd_download"]
 
 _lib = None
@@ -127,6 +127,8 @@ def lib():
         L.qpdo_amd_spmv.argtypes = [W, C.c_int, dp, dp]
         L.qpdo_amd_linesearch.argtypes = [W, C.c_double, C.c_double, dp, dp, dp]
         L.qpdo_amd_download.argtypes = [W, C.c_int, dp]
+        L.qpdo_amd_dist_config.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qpdo_amd_dist_unique_id.argtypes = [C.c_void_p]
         L.qpdo_amd_solve_batch.restype = C.c_long
         L.qpdo_amd_solve_batch.argtypes = [C.c_long, C.POINTER(BatchItem), C.POINTER(QPDOSettings), C.c_int]
         _lib = L
@@ -372,3 +374,37 @@ def solve_batch(probs, settings=None, nthreads=16, **kw):
         info["status"] = info["status"].decode()
         res.append(dict(info=info, x=x, y=y))
     return res, int(failed)
+
+
+# ---- one large QP row-partitioned over the ranks of a torch.distributed job ---------------------------------
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_long, C.c_int)
+_dist_keep = []
+
+
+def dist_config(rank, world, mode="rccl", group=None):
+    """Partition the rows of A over `world` ranks for the workspaces created next in this process.
+    mode 'rccl': all-reduce with RCCL on the solver stream (one GPU per rank); the unique id is created by rank 0
+    and broadcast over torch.distributed.  mode 'host': all-reduce through torch.distributed on host buffers
+    (gloo) - slow, for tests of the partition logic on a single GPU."""
+    L = lib()
+    if world <= 1:
+        return L.qpdo_amd_dist_config(0, 1, None, None, None)
+    import torch
+    import torch.distributed as dist
+    if mode == "host":
+        def _cb(ctx, buf, count, op):
+            a = np.ctypeslib.as_array(buf, shape=(count,))
+            t = torch.from_numpy(a)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM, group=group)
+        fn = ALLREDUCE_FN(_cb)
+        _dist_keep.append(fn)
+        return L.qpdo_amd_dist_config(rank, world, None, C.cast(fn, C.c_void_p), None)
+    uid = C.create_string_buffer(128)
+    if rank == 0:
+        if L.qpdo_amd_dist_unique_id(uid) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+    box = [bytes(uid.raw)]
+    dist.broadcast_object_list(box, src=0, group=group)
+    uid = C.create_string_buffer(box[0], 128)
+    _dist_keep.append(uid)
+    return L.qpdo_amd_dist_config(rank, world, C.cast(uid, C.c_void_p), None, None)

@@ -1,0 +1,43 @@
+"""Worker for tests/test_gpu_dist.py: two (or more) ranks share GPU 0; the row-partitioned solver exchanges
+through a gloo host callback.  Rank 0 compares with the oracle and prints one JSON line."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["QPDO_DEVICE"] = "0"
+import numpy as np                              # noqa: E402
+import torch.distributed as dist                # noqa: E402
+from oracle import binding as ob                # noqa: E402
+from qpdo_amd import problems, solver           # noqa: E402
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+assert solver.dist_config(rank, world, mode="host") == 0
+out = []
+for name, p, st in [("C1", problems.config_qp("C1"), dict(max_iter=200)),
+                    ("rand_eq", problems.random_qp(23, 150, 300, 0.05, 50), {}),
+                    ("kat_pinf", problems.infeasibility_kat("primal_infeasible"), dict(max_iter=100)),
+                    ("noscale", problems.random_qp(24, 300, 200, 0.03), dict(scaling=0))]:
+    r = solver.solve_problem(p, verbose=0, **st)
+    if rank == 0:
+        o = ob.OracleSolver(p, ob.default_settings(**st)); ro = o.solve()
+        ok_counts = (r["info"]["status_val"], r["info"]["iterations"], r["info"]["oterations"]) == \
+                    (ro["info"]["status_val"], ro["info"]["iterations"], ro["info"]["oterations"])
+        if r["info"]["status_val"] in (-3, -4):
+            err = 0.0
+        else:
+            err = float(max(np.abs(r["x"] - ro["x"]).max(), np.abs(r["y"] - ro["y"]).max()))
+        out.append(dict(name=name, ok_counts=bool(ok_counts), err=err, status=r["info"]["status_val"], linsolve=r["stats"]["linsolve"]))
+        o.close()
+    # every rank must hold the same solution
+    chk = np.nan_to_num(np.concatenate([r["x"], r["y"]]))
+    import torch
+    t = torch.from_numpy(chk.copy()); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t2 = torch.from_numpy(chk.copy()); dist.all_reduce(t2, op=dist.ReduceOp.MIN)
+    assert torch.equal(t, t2), "ranks disagree on the solution"
+if rank == 0:
+    print(json.dumps(out))
+dist.barrier()
+dist.destroy_process_group()
