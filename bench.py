@@ -34,6 +34,9 @@ def parse():
                     help="C4 (n=1e5,m=2e5,1%%: the config the metric is quoted on), C2, C1 ...")
     ap.add_argument("--max-time", type=float, default=float(os.environ.get("QPDO_BENCH_MAX_TIME", "0")),
                     help="settings.max_time per solve in seconds (0 = reference default, unlimited)")
+    ap.add_argument("--partition", default=os.environ.get("QPDO_BENCH_PARTITION", "independent"), choices=["independent", "rows"],
+                    help="N > 1: 'independent' = one QP per GPU, no collective (weak scaling, default); 'rows' = ONE QP whose "
+                         "rows of A are partitioned over the GPUs with an RCCL all-reduce per A' product (strong scaling)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="bound of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -98,8 +101,12 @@ def main():
     from qpdo_amd import problems, solver
     cfg = problems.CONFIGS[a.workload]
     t0 = time.time()
-    prob = problems.config_qp(a.workload, index=rank)
+    rows_mode = (a.partition == "rows" and world > 1)
+    prob = problems.config_qp(a.workload, index=0 if rows_mode else rank)
     t_gen = time.time() - t0
+    if rows_mode:      # every rank holds the same instance; the library keeps its row slice on the GPU
+        if solver.dist_config(rank, world, mode="rccl") != 0:
+            raise RuntimeError("qpdo_amd_dist_config failed")
     st = dict(verbose=0)
     if a.max_time > 0:
         st["max_time"] = a.max_time
@@ -129,6 +136,8 @@ def main():
     dt = time.time() - t0
     dt_max = allreduce(dist, [dt], "max")[0]
     tot_newton, tot_cg = allreduce(dist, [newton, cg], "sum")
+    if rows_mode:      # one QP: every rank counted the same passes
+        tot_newton, tot_cg = tot_newton / world, tot_cg / world
 
     last = r
     rp, rd = problems.kkt_residuals(prob, last["x"], last["y"]) if last["info"]["status_val"] not in (-3, -4) else (None, None)
@@ -163,14 +172,15 @@ def main():
             "unit": "newton_iters/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt_max / max(1, a.steps),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if rows_mode else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (seeded counter-based generator, qpdo_amd/csrc/qpdo_gen.c)",
             "config": {"workload": "%s: one random sparse QP per GPU, n=%d, m=%d, density=%g, cold start, reference "
                                    "default settings (eps_abs=1e-6, scaling=10)%s" % (
                                        a.workload, cfg["n"], cfg["m"], cfg["density"],
                                        (", max_time=%gs" % a.max_time) if a.max_time > 0 else ""),
                        "n": cfg["n"], "m": cfg["m"], "density": cfg["density"], "linsolve": "jacobi-pcg" if s.stats()["linsolve"] == 0 else "dense-ldlt",
-                       "parallelism": "independent QPs per GPU, no collective"},
+                       "parallelism": ("one QP, rows of A partitioned over the GPUs, RCCL all-reduce of A'y" if rows_mode
+                                       else "independent QPs per GPU, no collective")},
             "time_to_eps_s": dt_max / max(1, a.steps) if all(v == 1 for v in statuses) else None,
             "status_val": statuses, "iterations": iters, "oterations": oters, "newton_passes": tot_newton,
             "cg_iters": tot_cg, "kkt_prim": rp, "kkt_dual": rd,
