@@ -445,8 +445,8 @@ static void launch_spmv_slab(QpdoDev *d, const DevCsr &M, const double *x, Epi e
     const size_t lds = ((size_t)M.W + (size_t)M.rows_per_wg) * sizeof(double);
     static thread_local bool attr_set = false;   // per instantiation
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab<Epi, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab<Epi, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab<Epi, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab<Epi, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         attr_set = true;
     }
     if (M.ci16)
@@ -1157,7 +1157,7 @@ __global__ void k_pcg_p(int n, const Ctrl *__restrict__ ctrl, const double *__re
 // S = D_h^-1 + A_h P^-1 A_h'  (Woodbury; S is <= 64 x 64 and is inverted on the host once per pass).
 // The solution of K dx = rhs is unchanged; only the iteration count drops.
 // ------------------------------------------------------------------------------------------------
-static const int DEFL_MAX = 64;
+static const int DEFL_MAX = 256;
 // hist[b] = #{ i : dmax/2^(b+1) < d_i <= dmax/2^b },  b = 0..31
 __global__ __launch_bounds__(256) void k_defl_hist(int m, const double *__restrict__ dw, const Ctrl *ctrl, int *__restrict__ hist) {
     __shared__ int lh[32];
@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(64) void k_defl_v(const int *__restrict__ done, int
     if (threadIdx.x == 0) v[a] = sacc;
 }
 // w = S^-1 v (explicit inverse, row per lane), scattered to the m-vector th at the heavy rows
-__global__ __launch_bounds__(64) void k_defl_w(const int *__restrict__ done, int r, const double *__restrict__ Sinv, const double *__restrict__ v,
+__global__ __launch_bounds__(256) void k_defl_w(const int *__restrict__ done, int r, const double *__restrict__ Sinv, const double *__restrict__ v,
                                                const int *__restrict__ list, double *__restrict__ th) {
     if (done && *done) return;
     const int a = threadIdx.x;
@@ -1946,15 +1946,15 @@ int qdev_create_dist(QpdoDev **out, int device, int32_t n, int32_t m, const Qdev
 
 void qdev_destroy(QpdoDev *d) {
     if (!d) return;
-    hipSetDevice(d->device);
-    if (d->stream) hipStreamSynchronize(d->stream);
-    for (void *p : d->allocs) hipFree(p);
-    if (d->hctrl) hipHostFree(d->hctrl);
-    if (d->comm.hbuf) hipHostFree(d->comm.hbuf);
+    (void)hipSetDevice(d->device);
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
+    for (void *p : d->allocs) (void)hipFree(p);
+    if (d->hctrl) (void)hipHostFree(d->hctrl);
+    if (d->comm.hbuf) (void)hipHostFree(d->comm.hbuf);
     if (d->comm.nccl) ncclCommDestroy(d->comm.nccl);
-    if (d->ev0) hipEventDestroy(d->ev0);
-    if (d->ev1) hipEventDestroy(d->ev1);
-    if (d->stream) hipStreamDestroy(d->stream);
+    if (d->ev0) (void)hipEventDestroy(d->ev0);
+    if (d->ev1) (void)hipEventDestroy(d->ev1);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
 int qdev_sync(QpdoDev *d) { HIPCHK(hipSetDevice(d->device)); HIPCHK(hipStreamSynchronize(d->stream)); return 0; }
@@ -2264,8 +2264,10 @@ static int defl_build(QpdoDev *d) {
     // S and its inverse (host, r <= 64)
     hipLaunchKernelGGL(k_defl_S, dim3(r, r), dim3(64), 0, d->stream, r, (const int *)d->defl_list, d->Arc.rp, d->Arc.ci, d->Arc.val,
                        (const double *)d->pc_diag, (const double *)d->dc, d->defl_S);
-    static thread_local double S[DEFL_MAX * DEFL_MAX], L[DEFL_MAX * DEFL_MAX], Li[DEFL_MAX * DEFL_MAX], Si[DEFL_MAX * DEFL_MAX];
-    HIPCHK(hipMemcpyAsync(S, d->defl_S, sizeof(S), hipMemcpyDeviceToHost, d->stream));
+    static thread_local std::vector<double> Sv, Lv, Liv, Siv;
+    Sv.assign((size_t)DEFL_MAX * DEFL_MAX, 0.0); Lv.assign((size_t)DEFL_MAX * DEFL_MAX, 0.0); Liv.assign((size_t)DEFL_MAX * DEFL_MAX, 0.0); Siv.assign((size_t)DEFL_MAX * DEFL_MAX, 0.0);
+    double *S = Sv.data(), *L = Lv.data(), *Li = Liv.data(), *Si = Siv.data();
+    HIPCHK(hipMemcpyAsync(S, d->defl_S, (size_t)DEFL_MAX * DEFL_MAX * 8, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     const int N = DEFL_MAX;
     for (int i = 0; i < r; i++)                     // Cholesky S = L L'
@@ -2282,14 +2284,13 @@ static int defl_build(QpdoDev *d) {
             for (int q = c; q < i; q++) t -= L[i * N + q] * Li[q * N + c];
             Li[i * N + c] = t / L[i * N + i];
         }
-    memset(Si, 0, sizeof(Si));
     for (int i = 0; i < r; i++)                     // S^-1 = Li' Li
         for (int j = 0; j <= i; j++) {
             double t = 0.0;
             for (int q = i; q < r; q++) t += Li[q * N + i] * Li[q * N + j];
             Si[i * N + j] = t; Si[j * N + i] = t;
         }
-    HIPCHK(hipMemcpyAsync(d->defl_Sinv, Si, sizeof(Si), hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemcpyAsync(d->defl_Sinv, Si, (size_t)DEFL_MAX * DEFL_MAX * 8, hipMemcpyHostToDevice, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     d->defl_r = r;
     d->defl_passes++;
@@ -2300,7 +2301,7 @@ static int defl_apply(QpdoDev *d, const int *done, double *p_rz) {
     const int r = d->defl_r;
     hipLaunchKernelGGL(k_defl_v, dim3(r), dim3(64), 0, d->stream, done, r, (const int *)d->defl_list, d->Arc.rp, d->Arc.ci, d->Arc.val,
                        (const double *)d->pc_z, d->defl_v);
-    hipLaunchKernelGGL(k_defl_w, dim3(1), dim3(64), 0, d->stream, done, r, (const double *)d->defl_Sinv, (const double *)d->defl_v,
+    hipLaunchKernelGGL(k_defl_w, dim3(1), dim3(DEFL_MAX), 0, d->stream, done, r, (const double *)d->defl_Sinv, (const double *)d->defl_v,
                        (const int *)d->defl_list, d->defl_t);
     EpiDeflZ e{d->pc_diag, d->pc_r, d->pc_z, p_rz};
     if (done) launch_spmv_pcg(d, d->Ath, d->defl_t, e, true);
@@ -2355,23 +2356,23 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
                 // K p = sigma_f p + sum over ranks of ( Q_rows p  [rows n0..]  +  A_c,loc' (d_c .* A_c,loc p) )
                 HIPCHK(hipMemsetAsync(d->Kp_part, 0, (size_t)n * 8, d->stream));
                 if (k > 0) launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
-                if (sample) hipEventRecord(d->ev0, d->stream);
+                if (sample) (void)hipEventRecord(d->ev0, d->stream);
                 if (d->nloc > 0) launch_spmv_pcg(d, d->Qs, d->pc_p, EpiAddTo{d->Kp_part, d->n0}, false);
-                if (sample) hipEventRecord(d->ev1, d->stream);
+                if (sample) (void)hipEventRecord(d->ev1, d->stream);
                 if (k > 0) launch_spmv_pcg(d, d->Atc, d->tc, EpiAddTo{d->Kp_part, 0}, false);
                 rc = comm_allreduce(d, d->Kp_part, (size_t)n, 0); if (rc) return rc;
                 hipLaunchKernelGGL(k_pcg_dist_finish, dim3(g), dim3(BLK), 0, d->stream, n, done, (const double *)d->Kp_part, (const double *)d->pc_p,
                                    d->sigma_f, d->pc_Kp, P + P_PKP * PGRID);
             } else if (k > 0) {
                 launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
-                if (sample) hipEventRecord(d->ev0, d->stream);
+                if (sample) (void)hipEventRecord(d->ev0, d->stream);
                 launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQ{d->pc_p, d->sigma_f, d->pc_Kp}, false);
-                if (sample) hipEventRecord(d->ev1, d->stream);
+                if (sample) (void)hipEventRecord(d->ev1, d->stream);
                 launch_spmv_pcg(d, d->Atc, d->tc, EpiPcgAt{d->pc_p, d->pc_Kp, P + P_PKP * PGRID}, true);
             } else {
-                if (sample) hipEventRecord(d->ev0, d->stream);
+                if (sample) (void)hipEventRecord(d->ev0, d->stream);
                 launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQdot{d->pc_p, d->sigma_f, d->pc_Kp, P + P_PKP * PGRID}, true);
-                if (sample) hipEventRecord(d->ev1, d->stream);
+                if (sample) (void)hipEventRecord(d->ev1, d->stream);
             }
             LAUNCH(k_pcg_update, g, n, d->ctrl, P + P_PKP * PGRID, pKp_cnt, d->pc_p, d->pc_Kp, d->pc_diag, d->dx, d->pc_r, d->pc_z,
                    P + P_RZ * PGRID, P + P_RR * PGRID);

@@ -744,9 +744,9 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
         if (items[i].y) for (size_t k = 0; k < m; k++) items[i].y[k] = infeasible ? NAN : sy[k];
     }
 done:
-    if (dbase) hipFree(dbase);
-    if (dprobs) hipFree(dprobs);
-    if (stream) hipStreamDestroy(stream);
+    if (dbase) (void)hipFree(dbase);
+    if (dprobs) (void)hipFree(dprobs);
+    if (stream) (void)hipStreamDestroy(stream);
     return rc;
 }
 

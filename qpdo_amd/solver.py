@@ -154,18 +154,18 @@ def _as_dp(a):
     return None if a is None else a.ctypes.data_as(dp)
 
 
-def _sparse_view(M, stype, keep):
+def _sparse_view(M, stype, keep, index_dtype=np.int64):
     M = sp.csc_matrix(M)
     M.sort_indices()
-    p = np.ascontiguousarray(M.indptr, np.int64)
-    i = np.ascontiguousarray(M.indices, np.int64)
+    p = np.ascontiguousarray(M.indptr, index_dtype)
+    i = np.ascontiguousarray(M.indices, index_dtype)
     x = np.ascontiguousarray(M.data, np.float64)
     keep.extend([p, i, x])
     s = CholmodSparse()
     s.nrow, s.ncol, s.nzmax = M.shape[0], M.shape[1], max(1, len(x))
     s.p, s.i, s.x = p.ctypes.data, i.ctypes.data, x.ctypes.data
     s.nz, s.z = None, None
-    s.stype, s.itype, s.xtype, s.dtype, s.sorted, s.packed = stype, 2, 1, 0, 1, 1
+    s.stype, s.itype, s.xtype, s.dtype, s.sorted, s.packed = stype, (2 if index_dtype == np.int64 else 0), 1, 0, 1, 1
     return s
 
 
@@ -177,7 +177,7 @@ class QPDO:
         self.n = self.m = 0
 
     # qpdo.m:50-160
-    def setup(self, Q, q, A, l, u, settings=None, Qstype=None, c=0.0, **kw):
+    def setup(self, Q, q, A, l, u, settings=None, Qstype=None, c=0.0, index_dtype=np.int64, **kw):
         if self._w:
             raise RuntimeError("Solver is already initialized with problem data.")   # qpdo_mex.c:122-124
         A = sp.csc_matrix(A)
@@ -203,7 +203,7 @@ class QPDO:
                     raise KeyError("unrecognized solver setting '%s'" % k)
                 setattr(settings, k, v)
         keep = [q, l, u]
-        Qs, As = _sparse_view(Q, Qstype, keep), _sparse_view(A, 0, keep)
+        Qs, As = _sparse_view(Q, Qstype, keep, index_dtype), _sparse_view(A, 0, keep, index_dtype)
         data = QPDOData()
         data.n, data.m, data.Q, data.A = n, m, C.pointer(Qs), C.pointer(As)
         data.q, data.c, data.l, data.u = _as_dp(q), float(c), _as_dp(l), _as_dp(u)

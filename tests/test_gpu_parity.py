@@ -252,3 +252,37 @@ def test_fused_batch_known_answers(gpu_required):
         o = ob.OracleSolver(p, ob.default_settings(max_iter=100)); ro = o.solve()
         assert (r["info"]["iterations"], r["info"]["oterations"]) == (ro["info"]["iterations"], ro["info"]["oterations"])
         o.close()
+
+
+def test_matrix_storage_variants_give_identical_results(gpu_required):
+    """the ABI accepts Q as lower (stype -1, what the reference's mex passes), upper (+1) or full (0) storage
+    and int32 or int64 indices (reference DINT / DLONG builds): same instance, same bits out"""
+    import scipy.sparse as sp
+    p = problems.random_qp(51, 120, 200, 0.06)
+    Qf = problems.full_Q(p)
+    base = None
+    for Qm, st, idt in [(p["Q"], -1, np.int64), (sp.triu(Qf).tocsc(), 1, np.int64), (Qf, 0, np.int64), (p["Q"], -1, np.int32)]:
+        s = solver.QPDO().setup(Qm, p["q"], p["A"], p["l"], p["u"], Qstype=st, index_dtype=idt, verbose=0)
+        r = s.solve()
+        s.delete()
+        if base is None:
+            base = r
+        else:
+            assert r["info"]["iterations"] == base["info"]["iterations"]
+            assert np.array_equal(r["x"], base["x"]) and np.array_equal(r["y"], base["y"])
+
+
+def test_problem_without_constraints(gpu_required, linsolve):
+    """m = 0: the solve degenerates to (Q + sigma I) steps; every kernel must cope with empty m-vectors"""
+    import scipy.sparse as sp
+    p = problems.random_qp(52, 80, 1, 0.1)
+    p["A"] = sp.csc_matrix((0, 80)); p["l"] = np.zeros(0); p["u"] = np.zeros(0); p["m"] = 0
+    o = ob.OracleSolver(p, ob.default_settings())
+    ro = o.solve()
+    r = solver.solve_problem(p, verbose=0)
+    assert (r["info"]["status_val"], r["info"]["iterations"], r["info"]["oterations"]) == \
+           (ro["info"]["status_val"], ro["info"]["iterations"], ro["info"]["oterations"])
+    assert close_vec(r["x"], ro["x"], 1e-8)
+    Q = problems.full_Q(p)
+    assert np.abs(Q @ r["x"] + p["q"]).max() <= 1e-6
+    o.close()
