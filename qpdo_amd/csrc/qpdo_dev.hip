@@ -125,7 +125,7 @@ struct QpdoDev {
     // factor state
     double sigma_f = 0.0;
     // config
-    int linsolve = 0; double pcg_tol = 1e-12; int pcg_maxit = 100000; int pcg_batch = 16;
+    int linsolve = 0; double pcg_tol = 1e-12; int pcg_maxit = 100000; int pcg_batch = 16; int pcg_graph = 1;
     // stats
     QdevStats st{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1960,6 +1960,8 @@ void qdev_destroy(QpdoDev *d) {
 int qdev_sync(QpdoDev *d) { HIPCHK(hipSetDevice(d->device)); HIPCHK(hipStreamSynchronize(d->stream)); return 0; }
 
 int qdev_configure(QpdoDev *d, int linsolve, double pcg_tol, int pcg_maxit) {
+    const char *gr = getenv("QPDO_PCG_GRAPH");
+    if (gr && !strcmp(gr, "0")) d->pcg_graph = 0;
     const char *mx = getenv("QPDO_DENSE_MAX_N");
     if (mx && *mx) d->dense_max_n = atoi(mx);
     if (d->dense_max_n > 18000) d->dense_max_n = 18000;       // the assembly accumulator (n doubles) must fit in LDS
@@ -2346,48 +2348,75 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
     }
     LAUNCH(k_pcg_init2, 1, P + P_RZ * PGRID, cnt_rz, P + P_RR * PGRID, g, d->ctrl);
     const int pKp_cnt = dist ? vgrid(n) : (k > 0 ? spmv_pgrid(d->Atc) : spmv_pgrid(d->Qf));
+    // one PCG iteration as a sequence of launches on the backend stream
+    auto issue_iteration = [&](bool sample) -> int {
+        if (dist) {
+            // K p = sigma_f p + sum over ranks of ( Q_rows p  [rows n0..]  +  A_c,loc' (d_c .* A_c,loc p) )
+            HIPCHK(hipMemsetAsync(d->Kp_part, 0, (size_t)n * 8, d->stream));
+            if (k > 0) launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
+            if (sample) (void)hipEventRecord(d->ev0, d->stream);
+            if (d->nloc > 0) launch_spmv_pcg(d, d->Qs, d->pc_p, EpiAddTo{d->Kp_part, d->n0}, false);
+            if (sample) (void)hipEventRecord(d->ev1, d->stream);
+            if (k > 0) launch_spmv_pcg(d, d->Atc, d->tc, EpiAddTo{d->Kp_part, 0}, false);
+            int rcx = comm_allreduce(d, d->Kp_part, (size_t)n, 0); if (rcx) return rcx;
+            hipLaunchKernelGGL(k_pcg_dist_finish, dim3(g), dim3(BLK), 0, d->stream, n, done, (const double *)d->Kp_part, (const double *)d->pc_p,
+                               d->sigma_f, d->pc_Kp, P + P_PKP * PGRID);
+        } else if (k > 0) {
+            launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
+            if (sample) (void)hipEventRecord(d->ev0, d->stream);
+            launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQ{d->pc_p, d->sigma_f, d->pc_Kp}, false);
+            if (sample) (void)hipEventRecord(d->ev1, d->stream);
+            launch_spmv_pcg(d, d->Atc, d->tc, EpiPcgAt{d->pc_p, d->pc_Kp, P + P_PKP * PGRID}, true);
+        } else {
+            if (sample) (void)hipEventRecord(d->ev0, d->stream);
+            launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQdot{d->pc_p, d->sigma_f, d->pc_Kp, P + P_PKP * PGRID}, true);
+            if (sample) (void)hipEventRecord(d->ev1, d->stream);
+        }
+        LAUNCH(k_pcg_update, g, n, d->ctrl, P + P_PKP * PGRID, pKp_cnt, d->pc_p, d->pc_Kp, d->pc_diag, d->dx, d->pc_r, d->pc_z,
+               P + P_RZ * PGRID, P + P_RR * PGRID);
+        if (defl) defl_apply(d, done, P + P_RZ * PGRID);
+        LAUNCH(k_pcg_scalar, 1, d->ctrl, P + P_RZ * PGRID, cnt_rz, P + P_RR * PGRID, g, d->pcg_tol);
+        LAUNCH(k_pcg_p, g, n, d->ctrl, d->pc_z, d->pc_p);
+        return 0;
+    };
+    // Launch-bound regime (cache-resident matrices): replay a captured batch of iterations as a hipGraph.  The
+    // kernels leave immediately once the device-side latch is set, so replaying whole batches stays exact.
+    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+    const bool use_graph = d->pcg_graph && !dist && !d->Qf.use_slab && d->pcg_maxit >= d->pcg_batch;
+    if (use_graph) {
+        bool ok = hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            for (int b = 0; b < d->pcg_batch && ok; b++) ok = issue_iteration(false) == 0;
+            hipError_t e = hipStreamEndCapture(d->stream, &graph);
+            ok = ok && e == hipSuccess && graph;
+        }
+        if (ok) ok = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (!ok) { if (graph) (void)hipGraphDestroy(graph); graph = nullptr; gexec = nullptr; (void)hipGetLastError(); }
+    }
     int it = 0;
+    rc = 0;
     while (it < d->pcg_maxit) {
         const int it_before = it;
         int batch = d->pcg_batch; if (it + batch > d->pcg_maxit) batch = d->pcg_maxit - it;
-        for (int b = 0; b < batch; b++) {
-            const bool sample = (b == 0);
-            if (dist) {
-                // K p = sigma_f p + sum over ranks of ( Q_rows p  [rows n0..]  +  A_c,loc' (d_c .* A_c,loc p) )
-                HIPCHK(hipMemsetAsync(d->Kp_part, 0, (size_t)n * 8, d->stream));
-                if (k > 0) launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
-                if (sample) (void)hipEventRecord(d->ev0, d->stream);
-                if (d->nloc > 0) launch_spmv_pcg(d, d->Qs, d->pc_p, EpiAddTo{d->Kp_part, d->n0}, false);
-                if (sample) (void)hipEventRecord(d->ev1, d->stream);
-                if (k > 0) launch_spmv_pcg(d, d->Atc, d->tc, EpiAddTo{d->Kp_part, 0}, false);
-                rc = comm_allreduce(d, d->Kp_part, (size_t)n, 0); if (rc) return rc;
-                hipLaunchKernelGGL(k_pcg_dist_finish, dim3(g), dim3(BLK), 0, d->stream, n, done, (const double *)d->Kp_part, (const double *)d->pc_p,
-                                   d->sigma_f, d->pc_Kp, P + P_PKP * PGRID);
-            } else if (k > 0) {
-                launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
-                if (sample) (void)hipEventRecord(d->ev0, d->stream);
-                launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQ{d->pc_p, d->sigma_f, d->pc_Kp}, false);
-                if (sample) (void)hipEventRecord(d->ev1, d->stream);
-                launch_spmv_pcg(d, d->Atc, d->tc, EpiPcgAt{d->pc_p, d->pc_Kp, P + P_PKP * PGRID}, true);
-            } else {
-                if (sample) (void)hipEventRecord(d->ev0, d->stream);
-                launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQdot{d->pc_p, d->sigma_f, d->pc_Kp, P + P_PKP * PGRID}, true);
-                if (sample) (void)hipEventRecord(d->ev1, d->stream);
-            }
-            LAUNCH(k_pcg_update, g, n, d->ctrl, P + P_PKP * PGRID, pKp_cnt, d->pc_p, d->pc_Kp, d->pc_diag, d->dx, d->pc_r, d->pc_z,
-                   P + P_RZ * PGRID, P + P_RR * PGRID);
-            if (defl) defl_apply(d, done, P + P_RZ * PGRID);
-            LAUNCH(k_pcg_scalar, 1, d->ctrl, P + P_RZ * PGRID, cnt_rz, P + P_RR * PGRID, g, d->pcg_tol);
-            LAUNCH(k_pcg_p, g, n, d->ctrl, d->pc_z, d->pc_p);
+        if (gexec && batch == d->pcg_batch) {
+            hipError_t e = hipGraphLaunch(gexec, d->stream);
+            if (e != hipSuccess) { rc = set_err(e, "hipGraphLaunch", __LINE__); break; }
+            d->st.spmv_calls += (k > 0 ? 3 : 1) * (batch - 1);      // issue_iteration counted one batch during capture
+        } else {
+            for (int b = 0; b < batch && !rc; b++) rc = issue_iteration(b == 0 && !gexec);
+            if (rc) break;
         }
         it += batch;
-        rc = read_ctrl(d); if (rc) return rc;
-        if (d->hctrl->cnt[C_PCG_IT] > it_before) {      // the sampled (first) iteration of this batch really ran
+        rc = read_ctrl(d); if (rc) break;
+        if (!gexec && d->hctrl->cnt[C_PCG_IT] > it_before) {      // the sampled (first) iteration of this batch really ran
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, d->ev0, d->ev1) == hipSuccess) { d->ev_spmv_ms += ms; d->ev_spmv_n++; }
         }
         if (d->hctrl->cnt[C_PCG_DONE]) break;
     }
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc) return rc;
     *iters_out = d->hctrl->cnt[C_PCG_IT];
     return 0;
 }

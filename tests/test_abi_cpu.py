@@ -75,3 +75,14 @@ def test_generator_is_deterministic_and_psd():
     assert (a["l"] <= a["u"]).all()
     c3 = problems.config_qp("C3")
     assert (c3["l"][:120] == c3["u"][:120]).all() and (c3["l"][120:] < c3["u"][120:]).all()
+
+
+def test_problem_io_round_trip(tmp_path):
+    from qpdo_amd import io
+    p = problems.config_qp("C1b")
+    s = solver.default_settings(verbose=0, max_iter=123)
+    io.save_problem(tmp_path / "c1b.npz", p, s, result=dict(x=np.ones(p["n"]), y=np.zeros(p["m"]), info=dict(status_val=1, iterations=5, oterations=2)))
+    q, st, res = io.load_problem(tmp_path / "c1b.npz")
+    assert (q["A"] != p["A"]).nnz == 0 and (q["Q"] != p["Q"]).nnz == 0
+    assert np.array_equal(q["q"], p["q"]) and np.array_equal(q["l"], p["l"]) and q["Qstype"] == -1
+    assert st["max_iter"] == 123 and st["eps_abs"] == 1e-6 and res["info"]["iterations"] == 5

@@ -286,3 +286,15 @@ def test_problem_without_constraints(gpu_required, linsolve):
     Q = problems.full_Q(p)
     assert np.abs(Q @ r["x"] + p["q"]).max() <= 1e-6
     o.close()
+
+
+def test_verbose_iteration_lines(gpu_required, capfd):
+    """settings.verbose prints the reference's per-pass line (src/util.c:112-117) and the outer-update separators"""
+    p = problems.config_qp("C1b")
+    r = solver.solve_problem(p, verbose=1, print_interval=1)
+    out = capfd.readouterr().out
+    assert "iter |  objective     r.prim     r.dual |  r.p. in    r.d. in   stepsize |" in out
+    lines = [l for l in out.splitlines() if l.strip() and l.lstrip()[0].isdigit() and "|" in l]
+    assert len([l for l in lines if "---" not in l and "--  --" not in l]) >= r["info"]["iterations"]
+    assert len([l for l in lines if "|----" in l]) == r["info"]["oterations"]
+    assert "QPDO finished successfully." in out
