@@ -253,8 +253,8 @@ __global__ __launch_bounds__(256) void k_spmv(int nrows, const int *__restrict__
 // in LDS across slabs in a fixed order, so results are reproducible.
 // ------------------------------------------------------------------------------------------------
 static const int SLAB_THREADS = 1024;
-static const int SLAB_TPR = 16;
-template <class Epi, bool I16>
+static int g_slab_tpr = 8;      // lanes per row segment (QPDO_SLAB_TPR: 8 | 16 | 32; 8 measured best at C4)
+template <class Epi, bool I16, int TPR>
 __global__ __launch_bounds__(1024) void k_spmv_slab(const int *__restrict__ done, int nrows, int ncols, int nslabs, int W,
                                                     int rows_per_wg, const int *__restrict__ sp, const int *__restrict__ ci,
                                                     const unsigned short *__restrict__ ci16,
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(1024) void k_spmv_slab(const int *__restrict__ done
     const int row0 = blockIdx.x * rows_per_wg;
     const int R = min(rows_per_wg, nrows - row0);
     for (int r = tid; r < R; r += SLAB_THREADS) acc[r] = 0.0;
-    const int lane = tid & (SLAB_TPR - 1);
-    const int grp = tid / SLAB_TPR;
-    const int ngrp = SLAB_THREADS / SLAB_TPR;
+    const int lane = tid & (TPR - 1);
+    const int grp = tid / TPR;
+    const int ngrp = SLAB_THREADS / TPR;
     for (int s = 0; s < nslabs; s++) {
         const int c0 = s * W;
         const int cw = min(W, ncols - c0);
@@ -288,18 +288,18 @@ __global__ __launch_bounds__(1024) void k_spmv_slab(const int *__restrict__ done
             if (epi.skip(row)) continue;
             const int *spr = sp + (size_t)row * (nslabs + 1) + s;
             const int beg = spr[0], end = spr[1];
-            double s0 = 0.0, s1 = 0.0;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             int k = beg + lane;
-            for (; k + SLAB_TPR < end; k += 2 * SLAB_TPR) {
-                const double v0 = val[k], v1 = val[k + SLAB_TPR];
-                const int a0 = I16 ? (int)ci16[k] : ci[k] - c0, a1 = I16 ? (int)ci16[k + SLAB_TPR] : ci[k + SLAB_TPR] - c0;
-                s0 += v0 * xs[a0];
-                s1 += v1 * xs[a1];
+            for (; k + 3 * TPR < end; k += 4 * TPR) {
+                const double v0 = val[k], v1 = val[k + TPR], v2 = val[k + 2 * TPR], v3 = val[k + 3 * TPR];
+                const int a0 = I16 ? (int)ci16[k] : ci[k] - c0, a1 = I16 ? (int)ci16[k + TPR] : ci[k + TPR] - c0;
+                const int a2 = I16 ? (int)ci16[k + 2 * TPR] : ci[k + 2 * TPR] - c0, a3 = I16 ? (int)ci16[k + 3 * TPR] : ci[k + 3 * TPR] - c0;
+                s0 += v0 * xs[a0]; s1 += v1 * xs[a1]; s2 += v2 * xs[a2]; s3 += v3 * xs[a3];
             }
-            if (k < end) s0 += val[k] * xs[I16 ? (int)ci16[k] : ci[k] - c0];
-            double t = s0 + s1;
+            for (; k < end; k += TPR) s0 += val[k] * xs[I16 ? (int)ci16[k] : ci[k] - c0];
+            double t = (s0 + s1) + (s2 + s3);
 #pragma unroll
-            for (int o = SLAB_TPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, SLAB_TPR);
+            for (int o = TPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, TPR);
             if (lane == 0) acc[r] += t;
         }
     }
@@ -445,16 +445,15 @@ static void launch_spmv_slab(QpdoDev *d, const DevCsr &M, const double *x, Epi e
     const size_t lds = ((size_t)M.W + (size_t)M.rows_per_wg) * sizeof(double);
     static thread_local bool attr_set = false;   // per instantiation
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab<Epi, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab<Epi, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+#define SLAB_ATTR(I16, T) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab<Epi, I16, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)
+        SLAB_ATTR(false, 8); SLAB_ATTR(false, 16); SLAB_ATTR(false, 32); SLAB_ATTR(true, 8); SLAB_ATTR(true, 16); SLAB_ATTR(true, 32);
+#undef SLAB_ATTR
         attr_set = true;
     }
-    if (M.ci16)
-        hipLaunchKernelGGL((k_spmv_slab<Epi, true>), dim3(M.slab_grid), dim3(SLAB_THREADS), lds, d->stream, done, M.nrows, M.ncols, M.nslabs, M.W,
-                           M.rows_per_wg, M.sp, M.ci, M.ci16, M.val, x, epi);
-    else
-        hipLaunchKernelGGL((k_spmv_slab<Epi, false>), dim3(M.slab_grid), dim3(SLAB_THREADS), lds, d->stream, done, M.nrows, M.ncols, M.nslabs, M.W,
-                           M.rows_per_wg, M.sp, M.ci, M.ci16, M.val, x, epi);
+#define SLAB_GO(I16, T) hipLaunchKernelGGL((k_spmv_slab<Epi, I16, T>), dim3(M.slab_grid), dim3(SLAB_THREADS), lds, d->stream, done, M.nrows, M.ncols, M.nslabs, M.W, M.rows_per_wg, M.sp, M.ci, M.ci16, M.val, x, epi)
+    if (M.ci16) { if (g_slab_tpr == 8) SLAB_GO(true, 8); else if (g_slab_tpr == 32) SLAB_GO(true, 32); else SLAB_GO(true, 16); }
+    else        { if (g_slab_tpr == 8) SLAB_GO(false, 8); else if (g_slab_tpr == 32) SLAB_GO(false, 32); else SLAB_GO(false, 16); }
+#undef SLAB_GO
     d->st.spmv_calls++;
     d->st.spmv_bytes += (int64_t)M.alg_bytes();
 }
@@ -1710,6 +1709,8 @@ static int upload_csr(QpdoDev *d, DevCsr *M, const QdevCsr *h) {
 static int read_ctrl(QpdoDev *d);
 // decide whether M streams from HBM (then use the LDS-staged kernel) and build its slab pointers
 static int setup_slabs(QpdoDev *d, DevCsr *M) {
+    const char *tp = getenv("QPDO_SLAB_TPR");
+    if (tp && (atoi(tp) == 8 || atoi(tp) == 16 || atoi(tp) == 32)) g_slab_tpr = atoi(tp);
     const char *force = getenv("QPDO_SPMV");            // "slab" | "plain" | unset (auto)
     const double bytes = 12.0 * (double)M->nnz;
     bool want = bytes >= 192.0 * 1024 * 1024 && M->nrows >= 4096;   // beyond what L2 + Infinity Cache keep resident
