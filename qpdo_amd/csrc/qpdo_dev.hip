@@ -1493,21 +1493,23 @@ __device__ __forceinline__ void mfma_64x64x64(const double (*As)[80], const doub
 }
 // LDL' of the 64x64 diagonal block kb; writes unit-lower L back, D to Dg and the inverse of L
 // (column-major: Li[c*64 + r] = (L^-1)[r][c]) for the panel solve and the triangular solves.
-// Register-resident: thread (wave w, lane c) owns column c, rows w, w+4, ..., w+60 of the block (a) and of the
+// Register-resident: thread (wave w, lane c) owns column c, rows w, w+16, w+32, w+48 of the block (a) and of the
 // running inverse (x, Gauss-Jordan: the row operations of step j applied to the identity).  Per elimination
 // step the owners publish pivot column j+1 and inverse row j+1 through double-buffered LDS: one barrier a step.
-__global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ K, int ld, int kb, double *__restrict__ Dg, double *__restrict__ Linv) {
+#define DG_WAVES 16                       // 1024 threads: thread (wave w, lane c) owns column c, rows w, w+16, w+32, w+48
+#define DG_RPT (DNB / DG_WAVES)
+__global__ __launch_bounds__(1024) void k_ldl_diag(double *__restrict__ K, int ld, int kb, double *__restrict__ Dg, double *__restrict__ Linv) {
     __shared__ double colv[2][DNB];
     __shared__ double xrow[2][DNB];
     const int tid = threadIdx.x;
     const int c = tid & 63, w = tid >> 6;
     const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
-    double a[16], x[16];
+    double a[DG_RPT], x[DG_RPT];
 #pragma unroll
-    for (int rr = 0; rr < 16; rr++) { a[rr] = K[base + (w + 4 * rr) + (size_t)c * ld]; x[rr] = (w + 4 * rr == c) ? 1.0 : 0.0; }
+    for (int rr = 0; rr < DG_RPT; rr++) { a[rr] = K[base + (w + DG_WAVES * rr) + (size_t)c * ld]; x[rr] = (w + DG_WAVES * rr == c) ? 1.0 : 0.0; }
     if (c == 0) {
 #pragma unroll
-        for (int rr = 0; rr < 16; rr++) colv[0][w + 4 * rr] = a[rr];
+        for (int rr = 0; rr < DG_RPT; rr++) colv[0][w + DG_WAVES * rr] = a[rr];
     }
     if (w == 0) xrow[0][c] = x[0];                                 // row 0 of the identity
     __syncthreads();
@@ -1518,27 +1520,27 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ K, int ld
         if (c > j) {                                               // a_ic -= v_i v_c / d_j  for j < c <= i
             const double wc = cv[c] * inv_dj;
 #pragma unroll
-            for (int rr = 0; rr < 16; rr++) { const int i = w + 4 * rr; if (i >= c) a[rr] -= cv[i] * wc; }
+            for (int rr = 0; rr < DG_RPT; rr++) { const int i = w + DG_WAVES * rr; if (i >= c) a[rr] -= cv[i] * wc; }
         } else if (c == j) {                                       // column j becomes L(:,j) = v * (1/d_j), diagonal keeps d_j
 #pragma unroll
-            for (int rr = 0; rr < 16; rr++) { const int i = w + 4 * rr; if (i > j) a[rr] = a[rr] * inv_dj; }
+            for (int rr = 0; rr < DG_RPT; rr++) { const int i = w + DG_WAVES * rr; if (i > j) a[rr] = a[rr] * inv_dj; }
         }
 #pragma unroll
-        for (int rr = 0; rr < 16; rr++) { const int i = w + 4 * rr; if (i > j) x[rr] -= (cv[i] * inv_dj) * xj; }   // X(i,:) -= l_ij X(j,:)
+        for (int rr = 0; rr < DG_RPT; rr++) { const int i = w + DG_WAVES * rr; if (i > j) x[rr] -= (cv[i] * inv_dj) * xj; }   // X(i,:) -= l_ij X(j,:)
         if (c == j + 1) {                                          // publish the next pivot column (already updated)
 #pragma unroll
-            for (int rr = 0; rr < 16; rr++) colv[(j + 1) & 1][w + 4 * rr] = a[rr];
+            for (int rr = 0; rr < DG_RPT; rr++) colv[(j + 1) & 1][w + DG_WAVES * rr] = a[rr];
         }
-        if (w == ((j + 1) & 3)) {                                  // and row j+1 of the running inverse (final after this step)
+        if (w == ((j + 1) & (DG_WAVES - 1))) {                     // and row j+1 of the running inverse (final after this step)
 #pragma unroll
-            for (int rr = 0; rr < 16; rr++) if (w + 4 * rr == j + 1) xrow[(j + 1) & 1][c] = x[rr];
+            for (int rr = 0; rr < DG_RPT; rr++) if (w + DG_WAVES * rr == j + 1) xrow[(j + 1) & 1][c] = x[rr];
         }
         __syncthreads();
     }
     double *o = Linv + (size_t)kb * DNB * DNB;
 #pragma unroll
-    for (int rr = 0; rr < 16; rr++) {
-        const int i = w + 4 * rr;
+    for (int rr = 0; rr < DG_RPT; rr++) {
+        const int i = w + DG_WAVES * rr;
         if (i > c) K[base + i + (size_t)c * ld] = a[rr];
         if (i == c) Dg[kb * DNB + c] = a[rr];
         o[(size_t)c * DNB + i] = x[rr];
@@ -2449,7 +2451,7 @@ static int dense_factor(QpdoDev *d) {
     for (int J0 = 0; J0 < nb; J0 += DOUTER) {
         const int Jend = J0 + DOUTER < nb ? J0 + DOUTER : nb;
         for (int kb = J0; kb < Jend; kb++) {
-            hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), 0, d->stream, d->Kd, ld, kb, d->Dg, d->Linv);
+            hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(1024), 0, d->stream, d->Kd, ld, kb, d->Dg, d->Linv);
             const int below = nb - kb - 1;
             if (below > 0) {
                 hipLaunchKernelGGL(k_ldl_panel, dim3(below), dim3(256), 0, d->stream, d->Kd, ld, kb, kb - J0, (const double *)d->Dg,
