@@ -52,10 +52,14 @@ struct SmallQP {
     double *sol_x, *sol_y, *cert_dx, *cert_dy;
     QPDOInfo info;
     long newton_passes, factor_count;
+    long long *prof;                         // optional: per-phase wall-clock ticks (diagnostic runs only)
 };
 enum { NV_X = 0, NV_XBAR, NV_QX, NV_ATY, NV_DF, NV_RD, NV_RDI, NV_RHS, NV_DX, NV_QDX, NV_ATDY, NV_D, NV_DINV, NV_T, NV_COUNT };
 enum { MV_Y = 0, MV_YBAR, MV_AX, MV_MU, MV_ISQ, MV_W, MV_RP, MV_RPOLD, MV_RPI, MV_DY, MV_ADX, MV_DW, MV_E, MV_EINV, MV_ATS, MV_T, MV_COUNT };
 
+// diagnostic phase timer: lane 0 adds wall-clock ticks (100 MHz) to a buffer no other code reads
+#define PH(k) do { if (P.prof && threadIdx.x == 0) { const long long t_ = wall_clock64(); P.prof[k] += t_ - tph; tph = t_; } } while (0)
+enum { PH_RESID = 0, PH_OUTER, PH_PREP, PH_ASM, PH_FACTOR, PH_SOLVE, PH_SPMV, PH_LS, PH_UPDATE, PH_COUNT };
 #define FOR_T(i, N) for (int i = threadIdx.x; i < (N); i += blockDim.x)
 #define SYNC __syncthreads()
 
@@ -91,13 +95,19 @@ __device__ double norm_inf(const double *a, const double *b, int n, double *sm) 
     FOR_T(i, n) { double s = s_abs(b ? a[i] * b[i] : a[i]); mx = s > mx ? s : mx; }
     return blk_max(mx, sm);
 }
-// lin_alg.c:59-71 on one lane; result broadcast through LDS
-__device__ double dot_seq(const double *a, const double *b, int n, double *sm) {
+// lin_alg.c:59-71: prod += (a0b0 + a1b1 + a2b2 + a3b3) per 4-block, then the scalar tail.  The bracketed group
+// sums are independent, so all threads form them (into gbuf, LDS); one lane then adds the groups and the tail in
+// the reference's order - the result is bit-identical to the sequential loop.
+__device__ double dot_seq(const double *a, const double *b, int n, double *sm, double *gbuf) {
+    const int ng = n >> 2;
+    SYNC;
+    FOR_T(g, ng) { const int i = 4 * g; gbuf[g] = (a[i] * b[i] + a[i + 1] * b[i + 1] + a[i + 2] * b[i + 2] + a[i + 3] * b[i + 3]); }
+    FOR_T(t, n - 4 * ng) gbuf[ng + t] = a[4 * ng + t] * b[4 * ng + t];
     SYNC;
     if (threadIdx.x == 0) {
-        double prod = 0.0; int i = 0;
-        if (n >= 4) for (; i <= n - 4; i += 4) prod += (a[i] * b[i] + a[i + 1] * b[i + 1] + a[i + 2] * b[i + 2] + a[i + 3] * b[i + 3]);
-        for (; i < n; i++) prod += a[i] * b[i];
+        double prod = 0.0;
+        for (int g = 0; g < ng; g++) prod += gbuf[g];
+        for (int t = 0; t < n - 4 * ng; t++) prod += gbuf[ng + t];
         sm[16] = prod;
     }
     SYNC;
@@ -158,17 +168,18 @@ struct KView {
 };
 // assembly in the oracle's order: Q first, then rows r of A ascending (all threads share one row: every (i,j)
 // target of a row is distinct, rows are separated by a barrier), sigma_f last
-__device__ void small_assemble(SmallQP &P, const KView &kv, const double *dw, double sigma_f) {
+__device__ void small_assemble(SmallQP &P, const KView &kv, const double *dw, double sigma_f, const int *rp_s, double *d_s) {
     const int n = P.n, m = P.m;
     const size_t tot = kv.packed ? (size_t)n * (n + 1) / 2 : (size_t)n * n;
     for (size_t i = threadIdx.x; i < tot; i += blockDim.x) kv.K[i] = 0.0;
+    FOR_T(r, m) d_s[r] = dw[r];                    // weights of this pass into LDS: the row loop below reads them uniformly
     SYNC;
     FOR_T(r, n) for (int k = P.Qrp[r]; k < P.Qrp[r + 1]; k++) { const int cc = P.Qci[k]; if (r >= cc) kv.at(r, cc) += P.Qval[k]; }
     SYNC;
     for (int r = 0; r < m; r++) {
-        const double wgt = dw[r];
+        const double wgt = d_s[r];
         if (wgt == 0.0) continue;
-        const int b = P.Arp[r], len = P.Arp[r + 1] - b;
+        const int b = rp_s[r], len = rp_s[r + 1] - b;
         // pairs (a <= bb) of the row's entries: columns ascending, so Aci[b+bb] >= Aci[b+a]
         for (int pidx = threadIdx.x; pidx < len * len; pidx += blockDim.x) {
             const int a = pidx / len, bb = pidx % len;
@@ -180,24 +191,31 @@ __device__ void small_assemble(SmallQP &P, const KView &kv, const double *dw, do
     SYNC;
 }
 // left-looking by columns, natural order, no pivoting; K holds unit-lower L below and D on the diagonal
-__device__ void small_factor(SmallQP &P, const KView &kv, double *colbuf, double *tk) {
-    const int n = P.n;
-    for (int j = 0; j < n; j++) {
-        // t_k = l_jk d_k for k < j.  The reference skips k when l_jk == 0; subtracting x * 0 leaves the sum
-        // bit-for-bit unchanged, so the branch-free form below gives identical results.
-        FOR_T(k, j) tk[k] = kv.at(j, k) * kv.at(k, k);
-        SYNC;
-        FOR_T(ii, n - j) {
-            const int i = j + ii;
-            double s = kv.at(i, j);
-#pragma unroll 4
-            for (int k = 0; k < j; k++) s -= kv.at(i, k) * tk[k];
-            colbuf[i] = s;
+// PACKED: K is the packed lower triangle (in LDS); element (i, k) sits at off(k) + i with off(k+1) = off(k) + n - k - 1,
+// so the inner loop walks the row with an incremental 32-bit offset.  Separate instantiations keep the LDS
+// pointer provenance visible to the compiler (ds_read instead of flat loads).
+template <bool PACKED>
+__device__ __forceinline__ void small_factor_t(int n, double *__restrict__ K, double *__restrict__ lcol, double *__restrict__ tcol) {
+    // Right-looking (outer-product) LDL'.  Element (i,j) receives  -= l_ik * (l_jk d_k)  at step k, i.e. the same
+    // subtractions in the same ascending-k order as the left-looking reference loop - bit-identical results - but
+    // every step updates the whole trailing triangle, so all waves of the workgroup have work.
+    // (The reference skips k when l_jk == 0; subtracting x * 0 leaves an element unchanged bit for bit.)
+    const int li = threadIdx.x & 63, wj = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int offk = 0;                                   // off(k)
+    for (int k = 0; k < n; k++) {
+        const double dk = K[offk + k], inv = 1.0 / dk;
+        for (int i = k + 1 + (int)threadIdx.x; i < n; i += blockDim.x) {
+            const double l = K[offk + i] * inv;
+            K[offk + i] = l; lcol[i] = l; tcol[i] = l * dk;
         }
         SYNC;
-        const double inv = 1.0 / colbuf[j];
-        FOR_T(ii, n - j) { const int i = j + ii; kv.at(i, j) = (i == j) ? colbuf[j] : colbuf[i] * inv; }
+        for (int j = k + 1 + wj; j < n; j += nw) {
+            const double tj = tcol[j];
+            const int offj = PACKED ? j * n - (j * (j + 1)) / 2 : j * n;
+            for (int i = k + 1 + li; i < n; i += 64) if (i >= j) K[offj + i] -= lcol[i] * tj;
+        }
         SYNC;
+        offk += PACKED ? n - k - 1 : n;
     }
 }
 // x lives in LDS (xs) for the duration of the solve
@@ -222,15 +240,15 @@ __device__ void small_ldl_solve(SmallQP &P, const KView &kv, const double *b, do
 }
 
 // ---- linesearch (linesearch.c:8-158) -------------------------------------------------------------------
-__device__ double small_linesearch(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, unsigned char *jflag, double *tm, double *sm, u64 *skey, u32 *sidx) {
+__device__ double small_linesearch(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, unsigned char *jflag, double *tm, double *sm, u64 *skey, u32 *sidx, double *gbuf) {
     const int n = P.n, m = P.m;
     double *dy = V[MV_DY], *mu = V[MV_MU], *isq = V[MV_ISQ], *w = V[MV_W], *y = V[MV_Y], *Adx = V[MV_ADX];
     FOR_T(i, m) { double s = dy[i] * mu[i]; s = s * 0.5; tm[i] = s; }
-    double eta = dot_seq(dy, tm, m, sm);
-    eta += dot_seq(P.nv + (size_t)NV_DX * n, P.nv + (size_t)NV_QDX * n, n, sm);
+    double eta = dot_seq(dy, tm, m, sm, gbuf);
+    eta += dot_seq(P.nv + (size_t)NV_DX * n, P.nv + (size_t)NV_QDX * n, n, sm, gbuf);
     eta *= 0.5;
-    double beta = dot_seq(y, tm, m, sm);
-    beta += dot_seq(P.nv + (size_t)NV_DX * n, P.nv + (size_t)NV_DF * n, n, sm);
+    double beta = dot_seq(y, tm, m, sm, gbuf);
+    beta += dot_seq(P.nv + (size_t)NV_DX * n, P.nv + (size_t)NV_DF * n, n, sm, gbuf);
     beta *= 0.5;
     FOR_T(i, m) {
         double c0 = Adx[i] - tm[i]; c0 = c0 * isq[i];
@@ -322,7 +340,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
     __shared__ double sm[32];
     __shared__ u64 skey[2 * SM_MAX_M];
     __shared__ u32 sidx[2 * SM_MAX_M];
-    extern __shared__ __attribute__((aligned(16))) double dyn[];      // [xs: n][colbuf: n][tk: n][ls_delta: 2m][ls_alpha: 2m][jflag: 2m bytes][K packed, if it fits]
+    extern __shared__ __attribute__((aligned(16))) double dyn[];      // [xs: n][colbuf: n][tk: 2n][ls_delta: 2m][ls_alpha: 2m][jflag: 2m bytes][K packed, if it fits]
     if ((int)blockIdx.x >= count) return;
     SmallQP &P = probs[blockIdx.x];
     const int n = P.n, m = P.m;
@@ -336,13 +354,16 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
            *res_prim_old = V[MV_RPOLD], *res_prim_in = V[MV_RPI], *dy = V[MV_DY], *Adx = V[MV_ADX], *dw = V[MV_DW], *E = V[MV_E],
            *Einv = V[MV_EINV], *ats = V[MV_ATS], *tm = V[MV_T];
     int *active = P.iv, *active_old = P.iv + m, *changed = P.iv + 2 * m;
-    double *xs = dyn, *colbuf = dyn + n, *tk = dyn + 2 * (size_t)n, *ls_delta = dyn + 3 * (size_t)n, *ls_alpha = ls_delta + 2 * (size_t)m;
+    double *xs = dyn, *colbuf = dyn + n, *tk = dyn + 2 * (size_t)n, *gbuf = dyn + 4 * (size_t)n, *ls_delta = gbuf + (((size_t)(n > m ? n : m) / 4 + 4 + 1) & ~(size_t)1), *ls_alpha = ls_delta + 2 * (size_t)m;
     unsigned char *jflag = (unsigned char *)(ls_alpha + 2 * (size_t)m);
-    double *Klds = (double *)(jflag + (((size_t)2 * m + 15) & ~(size_t)15));
+    double *d_s = (double *)(jflag + (((size_t)2 * m + 15) & ~(size_t)15));
+    int *rp_s = (int *)(d_s + m);
+    double *Klds = (double *)(rp_s + (((size_t)m + 1 + 3) & ~(size_t)3));
     KView kv; kv.n = n; kv.packed = klds_ok; kv.K = klds_ok ? Klds : P.K;
     const int scaled = st.scaling > 0, prox = (int)st.proximal;
     double sc_c = 1.0, sc_cinv = 1.0;
 
+    FOR_T(r, m + 1) rp_s[r] = P.Arp[r];
     // ---- setup: workspace zero + scaling (qpdo.c:49-212) ----
     FOR_T(i, NV_COUNT * n) P.nv[i] = 0.0;
     FOR_T(i, MV_COUNT * m) P.mv[i] = 0.0;
@@ -368,7 +389,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
         SYNC;
     }
     {
-        const double f = 0.5 * dot_seq(x, Qx, n, sm) + dot_seq(P.q, x, n, sm);
+        const double f = 0.5 * dot_seq(x, Qx, n, sm, gbuf) + dot_seq(P.q, x, n, sm, gbuf);
         FOR_T(i, m) {
             const double r = Ax[i] - s_mid(Ax[i], P.l[i], P.u[i]);
             const double v = s_max(1e-3, s_min(1e3, 0.1 * s_max(1, 0.5 * r * r) / s_max(1, s_abs(f))));
@@ -385,6 +406,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
     int reset_newton = 1, factor_valid = 0, last_branch = -1; double last_sigma_f = -1.0;
     long iter = 0, oter = 0, iter_old = 0, status = QPDO_UNSOLVED, newton = 0, nfactor = 0;
     double rpn = 0, rdn = 0, rpin = 0, rdin = 0;
+    long long tph = P.prof ? wall_clock64() : 0;
     for (iter = 0; iter < st.max_iter; iter++) {
         // outer + inner residuals (iteration.c:30-93)
         FOR_T(i, m) {
@@ -412,6 +434,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
         if ((rpn > SM_INFTY) || (rdn > SM_INFTY)) { status = QPDO_NON_CVX; break; }
         if ((rpn <= st.eps_abs) && (rdn <= st.eps_abs)) { status = QPDO_SOLVED; break; }
         const int inner_opt = (rpin <= eps_in) && (rdin <= eps_in);
+        PH(PH_RESID);
         if (((iter > iter_old + 1) && inner_opt) || (iter == iter_old + st.inner_max_iter)) {
             if (iter < iter_old + st.inner_max_iter) {
                 if (st.eps_prim_inf > 0) {           // termination.c:97-151
@@ -462,7 +485,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
                             if (prox) { FOR_T(j, n) Qdx[j] = Qdx[j] + (-sigma * tau) * dx[j]; }
                             SYNC;
                             const double nq = norm_inf(Qdx, nullptr, n, sm);
-                            const double qdx = dot_seq(P.q, dx, n, sm);
+                            const double qdx = dot_seq(P.q, dx, n, sm, gbuf);
                             const double cc = scaled ? sc_c : 1.0;
                             if ((nq <= cc * eps) && (qdx <= -cc * eps)) {
                                 status = QPDO_DUAL_INFEASIBLE;
@@ -516,6 +539,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
             FOR_T(i, m) res_prim_old[i] = res_prim[i];
             SYNC;
             oter++; iter_old = iter;
+            PH(PH_OUTER);
         } else {
             if (st.reset_newton_iter > 0 && (iter % st.reset_newton_iter == 0)) reset_newton = 1;
             // active set, enter / leave (newton.c:96-126)
@@ -546,9 +570,11 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
             SYNC;
             FOR_T(j, n) rhs[j] = -res_dual_in[j] - Atdy[j];
             SYNC;
-            if (!factor_valid) { small_assemble(P, kv, dw, sigma_f); small_factor(P, kv, colbuf, tk); factor_valid = 1; nfactor++; }
+            PH(PH_PREP);
+            if (!factor_valid) { small_assemble(P, kv, dw, sigma_f, rp_s, d_s); PH(PH_ASM); if (klds_ok) small_factor_t<true>(n, Klds, colbuf, tk); else small_factor_t<false>(n, P.K, colbuf, tk); PH(PH_FACTOR); factor_valid = 1; nfactor++; }
             last_branch = branch; last_sigma_f = sigma_f;
             small_ldl_solve(P, kv, rhs, dx, xs);
+            PH(PH_SOLVE);
             spmv_rows(n, P.Qrp, P.Qci, P.Qval, dx, Qdx);
             spmv_rows(m, P.Arp, P.Aci, P.Aval, dx, Adx);
             SYNC;
@@ -557,11 +583,14 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
             SYNC;
             spmv_rows(n, P.Trp, P.Tci, P.Tval, dy, Atdy);
             SYNC;
-            tau = small_linesearch(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx);
+            PH(PH_SPMV);
+            tau = small_linesearch(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf);
+            PH(PH_LS);
             FOR_T(j, n) { x[j] = x[j] + tau * dx[j]; Qx[j] = Qx[j] + tau * Qdx[j]; Aty[j] = Aty[j] + tau * Atdy[j]; }
             FOR_T(i, m) { y[i] = y[i] + tau * dy[i]; Ax[i] = Ax[i] + tau * Adx[i]; }
             SYNC;
             newton++;
+            PH(PH_UPDATE);
         }
     }
     if (status == QPDO_UNSOLVED) status = QPDO_MAX_ITER_REACHED;
@@ -662,7 +691,7 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
     QPDOAmdBatchItem *items = (QPDOAmdBatchItem *)items_;
     const QPDOSettings *settings = (const QPDOSettings *)settings_;
     int rc = 0;
-    char *dbase = nullptr; hipStream_t stream = nullptr; SmallQP *dprobs = nullptr;
+    char *dbase = nullptr; hipStream_t stream = nullptr; SmallQP *dprobs = nullptr; long long *dprof = nullptr;
     std::vector<char> harena; std::vector<SmallQP> hp((size_t)count);
     std::vector<size_t> off_solx((size_t)count), off_soly((size_t)count), off_dx((size_t)count), off_dy((size_t)count);
     size_t total = 0;
@@ -717,11 +746,19 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
         p.K = (double *)(dbase + L.K);
         p.sol_x = (double *)(dbase + L.solx); p.sol_y = (double *)(dbase + L.soly); p.cert_dx = (double *)(dbase + L.dx); p.cert_dy = (double *)(dbase + L.dy);
     }
+    {
+        const char *pf = getenv("QPDO_SMALL_PROF");
+        if (pf && !strcmp(pf, "1")) {
+            SHIP(hipMalloc((void **)&dprof, (size_t)count * PH_COUNT * sizeof(long long)));
+            SHIP(hipMemsetAsync(dprof, 0, (size_t)count * PH_COUNT * sizeof(long long), stream));
+            for (long i = 0; i < count; i++) hp[(size_t)i].prof = dprof + i * PH_COUNT;
+        }
+    }
     SHIP(hipMemcpyAsync(dprobs, hp.data(), (size_t)count * sizeof(SmallQP), hipMemcpyHostToDevice, stream));
     {
         size_t nmax = 1, mmax = 0;
         for (long i = 0; i < count; i++) { if (items[i].data->n > nmax) nmax = items[i].data->n; if (items[i].data->m > mmax) mmax = items[i].data->m; }
-        size_t lds = 3 * nmax * 8 + 4 * mmax * 8 + ((2 * mmax + 15) & ~(size_t)15);
+        size_t lds = 4 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + 4 * mmax * 8 + ((2 * mmax + 15) & ~(size_t)15) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
         const size_t kbytes = nmax * (nmax + 1) / 2 * 8;
         const size_t budget = 160 * 1024 - 26 * 1024;          // static LDS: sort keys + indices + scratch
         const int klds_ok = (lds + kbytes <= budget) ? 1 : 0;
@@ -733,6 +770,16 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
     SHIP(hipMemcpyAsync(hp.data(), dprobs, (size_t)count * sizeof(SmallQP), hipMemcpyDeviceToHost, stream));
     SHIP(hipMemcpyAsync(harena.data(), dbase, upload_bytes, hipMemcpyDeviceToHost, stream));
     SHIP(hipStreamSynchronize(stream));
+    if (dprof) {   // diagnostic: phase shares of the longest-running item
+        std::vector<long long> hpf((size_t)count * PH_COUNT);
+        SHIP(hipMemcpy(hpf.data(), dprof, hpf.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        long best = 0; long long bt = -1;
+        for (long i = 0; i < count; i++) { long long t = 0; for (int k = 0; k < PH_COUNT; k++) t += hpf[(size_t)i * PH_COUNT + k]; if (t > bt) { bt = t; best = i; } }
+        static const char *nm[PH_COUNT] = {"resid", "outer", "prep", "assemble", "factor", "solve", "spmv", "linesearch", "update"};
+        fprintf(stderr, "[qpdo_small prof] item %ld, %ld passes, ticks(100MHz):", best, (long)hp[(size_t)best].info.iterations);
+        for (int k = 0; k < PH_COUNT; k++) fprintf(stderr, " %s=%.1fms", nm[k], hpf[(size_t)best * PH_COUNT + k] * 1e-5);
+        fprintf(stderr, "\n");
+    }
     for (long i = 0; i < count; i++) {
         const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
         const size_t n = d->n, m = d->m;
@@ -746,6 +793,7 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
 done:
     if (dbase) (void)hipFree(dbase);
     if (dprobs) (void)hipFree(dprobs);
+    if (dprof) (void)hipFree(dprof);
     if (stream) (void)hipStreamDestroy(stream);
     return rc;
 }
