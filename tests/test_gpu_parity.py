@@ -298,3 +298,32 @@ def test_verbose_iteration_lines(gpu_required, capfd):
     assert len([l for l in lines if "---" not in l and "--  --" not in l]) >= r["info"]["iterations"]
     assert len([l for l in lines if "|----" in l]) == r["info"]["oterations"]
     assert "QPDO finished successfully." in out
+
+
+def test_status_is_not_reset_between_solves_like_the_reference(gpu_required, monkeypatch):
+    """reference src/qpdo.c:451-453 vs :200: a second solve that runs out of iterations keeps the
+    SOLVED status of the first; QPDO_FIX_STATUS_RESET=1 switches the quirk off.  Oracle and HIP path agree."""
+    p = problems.config_qp("C1b")
+    o = ob.OracleSolver(p, ob.default_settings())
+    s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0)
+    assert o.solve()["info"]["status_val"] == 1 and s.solve()["info"]["status_val"] == 1
+    o.update_settings(ob.default_settings(max_iter=2)); s.update_settings(max_iter=2)
+    ro, rg = o.solve(), s.solve()
+    assert ro["info"]["iterations"] == rg["info"]["iterations"] == 2
+    assert ro["info"]["status_val"] == rg["info"]["status_val"] == 1          # stale status, as in the reference
+    s.delete(); o.close()
+    monkeypatch.setenv("QPDO_FIX_STATUS_RESET", "1")
+    s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0)
+    s.solve(); s.update_settings(max_iter=2)
+    assert s.solve()["info"]["status_val"] == -5
+    s.delete()
+
+
+def test_update_bounds_rejects_crossed_bounds(gpu_required):
+    """reference src/qpdo.c:526-536: l > u => QPDO_ERROR and the stored bounds stay untouched"""
+    p = problems.config_qp("C1b")
+    s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0)
+    before = s.download("l")
+    s.update_bounds(p["u"] + 1.0, p["u"])
+    assert s.info()["status_val"] == -99 and np.array_equal(s.download("l"), before)
+    s.delete()
