@@ -327,3 +327,45 @@ def test_update_bounds_rejects_crossed_bounds(gpu_required):
     s.update_bounds(p["u"] + 1.0, p["u"])
     assert s.info()["status_val"] == -99 and np.array_equal(s.download("l"), before)
     s.delete()
+
+
+def _lp_like(seed, n, m, qdiag):
+    import scipy.sparse as sp
+    p = problems.random_qp(seed, n, m, 0.1)
+    p["Q"] = sp.diags(np.full(n, qdiag)).tocsc() if qdiag > 0 else sp.csc_matrix((n, n))
+    return p
+
+
+@pytest.mark.parametrize("qdiag", [0.0, 1e-3])
+def test_lp_and_diagonal_q(qdiag, linsolve, gpu_required):
+    """Q = 0 (an LP: the proximal term alone makes the Newton system definite) and a weak diagonal Q"""
+    p = _lp_like(61, 40, 120, qdiag)
+    o = ob.OracleSolver(p, ob.default_settings(max_iter=400))
+    ro = o.solve()
+    r = solver.solve_problem(p, verbose=0, max_iter=400)
+    assert (r["info"]["status_val"], r["info"]["iterations"], r["info"]["oterations"]) == \
+           (ro["info"]["status_val"], ro["info"]["iterations"], ro["info"]["oterations"])
+    if ro["info"]["status_val"] == 1:
+        assert close_vec(r["x"], ro["x"], 1e-7) and close_vec(r["y"], ro["y"], 1e-7)
+    o.close()
+
+
+def test_constructed_primal_infeasible_instance(linsolve, gpu_required):
+    """two identical rows with disjoint bounds: no x satisfies both; the certificate path (reference
+    src/termination.c:97-151) must fire with the same pass counts as the oracle"""
+    import scipy.sparse as sp
+    p = problems.random_qp(62, 30, 60, 0.15)
+    A = p["A"].tolil()
+    A[1, :] = A[0, :]
+    p["A"] = A.tocsc()
+    p["l"][0], p["u"][0] = 1.0, 2.0
+    p["l"][1], p["u"][1] = -2.0, -1.0
+    o = ob.OracleSolver(p, ob.default_settings(max_iter=500))
+    ro = o.solve()
+    r = solver.solve_problem(p, verbose=0, max_iter=500)
+    assert ro["info"]["status_val"] == -3
+    assert (r["info"]["status_val"], r["info"]["iterations"], r["info"]["oterations"]) == \
+           (ro["info"]["status_val"], ro["info"]["iterations"], ro["info"]["oterations"])
+    dy = r["prim_inf_cert"]
+    assert np.abs(p["A"].T @ dy).max() <= 1e-5 * np.abs(dy).max()
+    o.close()
