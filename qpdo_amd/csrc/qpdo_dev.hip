@@ -261,6 +261,7 @@ __global__ __launch_bounds__(1024) void k_spmv_slab(const int *__restrict__ done
                                                     const double *__restrict__ val, const double *__restrict__ x, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sm[32];
+    __shared__ int next_row;
     if (done && *done) return;
     double *xs = lds;
     double *acc = lds + W;
@@ -269,8 +270,6 @@ __global__ __launch_bounds__(1024) void k_spmv_slab(const int *__restrict__ done
     const int R = min(rows_per_wg, nrows - row0);
     for (int r = tid; r < R; r += SLAB_THREADS) acc[r] = 0.0;
     const int lane = tid & (TPR - 1);
-    const int grp = tid / TPR;
-    const int ngrp = SLAB_THREADS / TPR;
     for (int s = 0; s < nslabs; s++) {
         const int c0 = s * W;
         const int cw = min(W, ncols - c0);
@@ -281,9 +280,21 @@ __global__ __launch_bounds__(1024) void k_spmv_slab(const int *__restrict__ done
             double2 *dst = reinterpret_cast<double2 *>(xs);
             for (int i = tid; i < pairs; i += SLAB_THREADS) dst[i] = src[i];
             if ((cw & 1) && tid == 0) xs[cw - 1] = x[c0 + cw - 1];
+            if (tid == 0) next_row = 0;
         }
         __syncthreads();
-        for (int r = grp; r < R; r += ngrp) {
+        // Rows are handed out dynamically (LDS counter): with only a few row segments per lane group and slab a
+        // static split leaves groups idle at the end-of-slab barrier.  One lane per WAVE grabs a batch of 64/TPR
+        // rows and broadcasts it wave-wide, so the loop exit is wave-uniform (no divergent break around the
+        // shuffles).  Which group takes a row does not change the row's arithmetic: results stay reproducible.
+        const int gw = (tid & 63) / TPR;                 // group index inside the wave
+        for (;;) {
+            int base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(&next_row, 64 / TPR);
+            base = __shfl(base, 0, 64);
+            if (base >= R) break;
+            const int r = base + gw;
+            if (r >= R) continue;
             const int row = row0 + r;
             if (epi.skip(row)) continue;
             const int *spr = sp + (size_t)row * (nslabs + 1) + s;
