@@ -1595,42 +1595,77 @@ __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ K, int l
 }
 // update on the matrix cores: C(ti,tj) -= sum_{q<nkb} W(ti, wcol0+q) * L(tj, kb0+q)'  for tj in [tj_lo, tj_hi), ti >= tj.
 // nkb = 1 updates the rest of the current 256-wide outer panel, nkb = 4 the trailing matrix (one read-modify-write
-// of C per 256 eliminated columns instead of per 64).
+// of C per 256 eliminated columns instead of per 64).  Software pipelined: the k dimension is cut into 32-deep
+// chunks held in double-buffered LDS tiles; the global loads of chunk c+1 are in flight while the MFMAs of chunk c
+// run (one barrier per chunk; 16-deep chunks: 40 KB LDS => four workgroups per CU, 32-deep: 80 KB => two).
+template <int SY_KC>
 __global__ __launch_bounds__(256) void k_ldl_syrk(double *__restrict__ K, int ld, const double *__restrict__ W, int kb0, int nkb, int wcol0,
                                                   int tj_lo, int tj_hi) {
     const int ti = tj_lo + blockIdx.x, tj = tj_lo + blockIdx.y;
     if (tj >= tj_hi || tj > ti) return;
-    __shared__ double As[DNB][80];
-    __shared__ double Bs[DNB][80];
+    // one LDS array: A tiles [buf][k][row] at S + buf*T, B tiles at S + (2+buf)*T, T = SY_KC*80 (row stride 80 doubles: the
+    // two k-rows of a half-wave hit disjoint banks); reused as the [col][row] image of the C tile in the epilogue
+    constexpr int T = SY_KC * 80;
+    constexpr int SZ = (4 * T > DNB * (DNB + 1)) ? 4 * T : DNB * (DNB + 1);
+    __shared__ double S[SZ];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, l = tid & 63;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
     const int li = l & 15, lk = l >> 4;
+    const int lr = tid & 63, lk0 = tid >> 6;                      // this thread stages rows lr, k = lk0 + 4 e
+    const int nch = nkb * (DNB / SY_KC);
+    const double *Wp = W + (size_t)ti * DNB + lr, *Kp = K + (size_t)tj * DNB + lr;
+    double ra[SY_KC / 4], rb[SY_KC / 4];
+    auto gload = [&](int ch) {
+        const int q = ch / (DNB / SY_KC), h = ch % (DNB / SY_KC);
+        const size_t wc0 = ((size_t)(wcol0 + q) * DNB + (size_t)h * SY_KC) * ld, kc0 = ((size_t)(kb0 + q) * DNB + (size_t)h * SY_KC) * ld;
+#pragma unroll
+        for (int e = 0; e < SY_KC / 4; e++) { const size_t ko = (size_t)(lk0 + 4 * e) * ld; ra[e] = Wp[wc0 + ko]; rb[e] = Kp[kc0 + ko]; }
+    };
+    auto lstore = [&](int buf) {
+        double *A = S + buf * T, *B = S + (2 + buf) * T;
+#pragma unroll
+        for (int e = 0; e < SY_KC / 4; e++) { A[(lk0 + 4 * e) * 80 + lr] = ra[e]; B[(lk0 + 4 * e) * 80 + lr] = rb[e]; }
+    };
     dvec4 acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int q = 0; q < 2; q++) acc[m][q] = (dvec4){0.0, 0.0, 0.0, 0.0};
-    for (int q = 0; q < nkb; q++) {
-        __syncthreads();
-        for (int idx = tid; idx < DNB * DNB; idx += 256) {
-            const int r = idx % DNB, k = idx / DNB;
-            As[k][r] = W[(size_t)ti * DNB + r + ((size_t)(wcol0 + q) * DNB + k) * ld];
-            Bs[k][r] = K[(size_t)tj * DNB + r + ((size_t)(kb0 + q) * DNB + k) * ld];
+    gload(0); lstore(0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ch++) {
+        const int buf = ch & 1;
+        const double *A = S + buf * T, *B = S + (2 + buf) * T;
+        if (ch + 1 < nch) gload(ch + 1);                         // in flight during the MFMAs below
+#pragma unroll
+        for (int k0 = 0; k0 < SY_KC; k0 += 4) {
+            const double a0 = A[(k0 + lk) * 80 + wr + li], a1 = A[(k0 + lk) * 80 + wr + 16 + li];
+            const double b0 = B[(k0 + lk) * 80 + wc + li], b1 = B[(k0 + lk) * 80 + wc + 16 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (ch + 1 < nch) lstore(buf ^ 1);
         __syncthreads();
-        mfma_64x64x64(As, Bs, acc, wr, wc, li, lk);
     }
+    // C -= acc, coalesced: the accumulators (4 rows x 16 columns per wave instruction) go through LDS as a [col][row]
+    // image so that the global read-modify-write runs along the contiguous rows
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int q = 0; q < 2; q++)
 #pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const int row = wr + m * 16 + lk + 4 * v, col = wc + q * 16 + li;
-                double *cp = K + (size_t)ti * DNB + row + ((size_t)tj * DNB + col) * ld;
-                *cp = *cp - acc[m][q][v];
-            }
+            for (int v = 0; v < 4; v++) S[(wc + q * 16 + li) * (DNB + 1) + wr + m * 16 + lk + 4 * v] = acc[m][q][v];
+    __syncthreads();
+    double *Cp = K + (size_t)ti * DNB + lr + (size_t)tj * DNB * ld;
+#pragma unroll 4
+    for (int e = 0; e < DNB / 4; e++) {
+        const int col = lk0 + 4 * e;
+        double *cp = Cp + (size_t)col * ld;
+        *cp = *cp - S[col * (DNB + 1) + lr];
+    }
 }
 // forward step kb: z_k = L_kk^-1 x_k (matrix-vector with the stored inverse: no serial chain), wave 0 publishes
 // it, then wave b updates the 64 rows of block kb+1+b:  x_i -= L(i, kb) z_k.
@@ -2457,6 +2492,7 @@ static int dense_factor(QpdoDev *d) {
     int rc = dense_alloc(d); if (rc) return rc;
     const int n = d->n, ld = d->dense_ld, nb = d->dense_nblk;
     const int g = ld < 1024 ? ld : 1024;
+    static const bool kc16 = [] { const char *e = getenv("QPDO_SYRK_KC"); return !(e && atoi(e) == 32); }();
     hipLaunchKernelGGL(k_dense_assemble, dim3(g), dim3(64), (size_t)n * sizeof(double), d->stream, n, ld, d->Qf.rp, d->Qf.ci, d->Qf.val,
                        d->At.rp, d->At.ci, d->At.val, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)d->d, d->sigma_f, d->Kd);
     for (int J0 = 0; J0 < nb; J0 += DOUTER) {
@@ -2467,14 +2503,16 @@ static int dense_factor(QpdoDev *d) {
             if (below > 0) {
                 hipLaunchKernelGGL(k_ldl_panel, dim3(below), dim3(256), 0, d->stream, d->Kd, ld, kb, kb - J0, (const double *)d->Dg,
                                    (const double *)d->Linv, d->Wd);
-                if (kb + 1 < Jend)      // rest of this outer panel
-                    hipLaunchKernelGGL(k_ldl_syrk, dim3(nb - (kb + 1), Jend - (kb + 1)), dim3(256), 0, d->stream, d->Kd, ld, (const double *)d->Wd,
-                                       kb, 1, kb - J0, kb + 1, Jend);
+                if (kb + 1 < Jend) {    // rest of this outer panel
+                    if (kc16) hipLaunchKernelGGL(k_ldl_syrk<16>, dim3(nb - (kb + 1), Jend - (kb + 1)), dim3(256), 0, d->stream, d->Kd, ld, (const double *)d->Wd, kb, 1, kb - J0, kb + 1, Jend);
+                    else      hipLaunchKernelGGL(k_ldl_syrk<32>, dim3(nb - (kb + 1), Jend - (kb + 1)), dim3(256), 0, d->stream, d->Kd, ld, (const double *)d->Wd, kb, 1, kb - J0, kb + 1, Jend);
+                }
             }
         }
-        if (Jend < nb)                  // trailing matrix: all columns of the outer panel at once
-            hipLaunchKernelGGL(k_ldl_syrk, dim3(nb - Jend, nb - Jend), dim3(256), 0, d->stream, d->Kd, ld, (const double *)d->Wd, J0, Jend - J0, 0,
-                               Jend, nb);
+        if (Jend < nb) {                // trailing matrix: all columns of the outer panel at once
+            if (kc16) hipLaunchKernelGGL(k_ldl_syrk<16>, dim3(nb - Jend, nb - Jend), dim3(256), 0, d->stream, d->Kd, ld, (const double *)d->Wd, J0, Jend - J0, 0, Jend, nb);
+            else      hipLaunchKernelGGL(k_ldl_syrk<32>, dim3(nb - Jend, nb - Jend), dim3(256), 0, d->stream, d->Kd, ld, (const double *)d->Wd, J0, Jend - J0, 0, Jend, nb);
+        }
     }
     HIPCHK(hipGetLastError());
     d->dense_valid = 1;
