@@ -8,6 +8,8 @@
  * Environment variables read once per qpdo_setup:
  *   QPDO_DEVICE      HIP device ordinal (default: LOCAL_RANK if set, else 0)
  *   QPDO_LINSOLVE    "pcg" | "dense" | "auto" (default auto: dense LDL' for n <= QPDO_DENSE_MAX_N = 8192)
+ *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change instead of the low-rank update of the kept dense factor
+ *   QPDO_DENSE_LOOKAHEAD "0": factor on one stream (no overlap of the next panel with the trailing update)
  *   QPDO_SPMV        "slab" | "plain" (default: LDS-staged slab kernel for matrices >= 192 MB)
  *   QPDO_DEFLATE     "0" disables the heavy-row deflation of the PCG preconditioner
  *   QPDO_IDX16       "0" disables the 16-bit slab-local column indices
@@ -45,6 +47,9 @@ typedef struct {
     long   linsolve;        /* 0 pcg, 1 dense                                              */
     double spmv_Q_avg_s;    /* HIP-event average duration of the sampled Q SpMV inside PCG */
     long   spmv_Q_samples;
+    long   lowrank_solves;  /* dense solves through the low-rank update of the kept factor (cholmod_interface.c:57-93) */
+    long   lowrank_cols;    /* rows that entered the low-rank set (one multi-RHS solve column each)                 */
+    long   lowrank_rejects; /* low-rank solves abandoned for a refactorization (ill-conditioned downdate)          */
 } QPDOAmdStats;
 
 int  qpdo_amd_device_count(void);

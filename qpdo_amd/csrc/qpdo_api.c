@@ -749,6 +749,9 @@ int qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out) {
     out->linsolve = st.linsolve;
     out->spmv_Q_avg_s = avg;
     out->spmv_Q_samples = ns;
+    out->lowrank_solves = (long)st.lowrank_solves;
+    out->lowrank_cols = (long)st.lowrank_cols;
+    out->lowrank_rejects = (long)st.lowrank_rejects;
     return 0;
 }
 

@@ -42,6 +42,9 @@ typedef struct {
     int64_t spmv_bytes;         /* algorithmic bytes moved by those launches */
     int64_t factor_count;       /* dense LDL' factorizations                 */
     int32_t linsolve;           /* 0 pcg, 1 dense                            */
+    int64_t lowrank_solves;     /* dense solves that used the low-rank update of the kept factor */
+    int64_t lowrank_cols;       /* rows that received a low-rank slot (multi-RHS solve columns)   */
+    int64_t lowrank_rejects;    /* low-rank solves abandoned for a refactorization (tiny pivot)   */
 } QdevStats;
 
 int qdev_device_count(void);

@@ -101,6 +101,12 @@ struct QpdoDev {
     int dense_ld = 0, dense_nblk = 0, dense_valid = 0;
     int dense_max_n = 8192;   // measured crossover with deflated PCG: n ~ 8e3
     double *Kd = nullptr, *Wd = nullptr, *Dg = nullptr, *Linv = nullptr, *dz = nullptr, *dxw = nullptr;
+    hipStream_t stream2 = nullptr;            // dense factor look-ahead: trailing updates run here
+    // low-rank factor update (Woodbury on the kept factor): see the k_wb_* kernels
+    int dense_factored = 0, wb_enable = 1, wb_k = 0; double dense_fact_sigma = 0.0;
+    double *d_fact = nullptr, *wb_Z = nullptr, *wb_T = nullptr, *wb_G = nullptr, *wb_v = nullptr, *wb_w = nullptr, *wb_t = nullptr;
+    int *wb_slot = nullptr, *wb_rows = nullptr, *wb_cnt = nullptr;
+    hipEvent_t evF[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr};
     int dense_last_branch = -1; double dense_last_sigma = -1.0;
     // n-vectors
     double *x, *xbar, *Qx, *Aty, *q, *df, *res_dual, *res_dual_in, *rhs, *dx, *Qdx, *Atdy, *D, *Dinv;
@@ -1557,6 +1563,42 @@ __global__ __launch_bounds__(1024) void k_ldl_diag(double *__restrict__ K, int l
         o[(size_t)c * DNB + i] = x[rr];
     }
 }
+// Two-wave variant: lane i of wave 0 keeps row i of the block, lane i of wave 1 column i of the running inverse,
+// both as 64 registers (fully unrolled: every register index is a constant).  Step j: wave 0 publishes column j
+// through LDS, every lane reads it back as broadcasts and applies  r_c -= (r_j / d_j) v_c  for c > j -- for wave 0
+// that is a_ic -= l_ij v_c, for wave 1 the row operation X(c,i) -= l_cj X(j,i) of Gauss-Jordan on the identity.
+// A step costs one two-wave barrier and one LDS round trip instead of a 16-wave barrier.  The two roles differ
+// only by selects, never by branches around the register array (divergent copies of it spill).
+__global__ __launch_bounds__(128) void k_ldl_diag1(double *__restrict__ K, int ld, int kb, double *__restrict__ Dg, double *__restrict__ Linv) {
+    __shared__ double colb[2][DNB];
+    __shared__ double Ts[DNB][DNB + 1];
+    const int i = threadIdx.x & 63;
+    const bool is_a = threadIdx.x < 64;
+    const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
+    double r[DNB];
+#pragma unroll
+    for (int c = 0; c < DNB; c++) { const double v = K[base + i + (size_t)c * ld]; r[c] = is_a ? v : ((c == i) ? 1.0 : 0.0); }
+#pragma unroll
+    for (int j = 0; j < DNB; j++) {
+        double *cb = colb[j & 1];
+        if (is_a) cb[i] = r[j];                                    // v_i = A(i,j), rows i >= j are current
+        __syncthreads();
+        const double inv = 1.0 / cb[j];
+        const double sj = r[j] * inv;                              // l_ij (wave 0) or X(j,i)/d_j (wave 1)
+#pragma unroll
+        for (int c = j + 1; c < DNB; c++) r[c] = fma(-sj, cb[c], r[c]);
+        r[j] = (is_a && i > j) ? sj : r[j];                        // lane j keeps d_j in r[j]
+    }
+#pragma unroll
+    for (int c = 0; c < DNB; c++) {
+        if (is_a && i > c) K[base + i + (size_t)c * ld] = r[c];
+        if (is_a && i == c) Dg[kb * DNB + c] = r[c];
+        if (!is_a) Ts[i][c] = r[c];
+    }
+    __syncthreads();
+    double *o = Linv + (size_t)kb * DNB * DNB;
+    for (int e = threadIdx.x; e < DNB * DNB; e += 128) { const int c = e >> 6, q = e & 63; o[(size_t)c * DNB + q] = Ts[c][q]; }
+}
 // panel below the diagonal block on the matrix cores: X = A L_kk^-T  =>  W = X (= L D), L = X / D.
 // One workgroup per 64-row tile.
 __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ K, int ld, int kb, int wcol, const double *__restrict__ Dg,
@@ -1711,6 +1753,262 @@ __global__ __launch_bounds__(64) void k_ldl_bwd(const double *__restrict__ K, in
     double sacc = y[j * DNB + l];
     for (int r = 0; r < DNB; r++) sacc -= tile[r][l] * xs[r];
     y[j * DNB + l] = sacc;
+}
+// ---- multi right-hand-side block solves (MFMA) and the low-rank factor update -------------------------
+// The reference keeps its factor current with rank-<=100 LDL' up/downdates when few rows enter or leave
+// (cholmod_interface.c:57-93, newton.c:21-30).  Here the factor K0 = L D L' of the last full factorization
+// is kept and the change K = K0 + U' W U (U = the rows of A whose weight d_i moved since then, W = diag(d - d_fact))
+// is applied in the solve:  K^-1 r = z0 - Z (I + W G)^-1 W U z0,  z0 = K0^-1 r,  Z = K0^-1 U',  G = U Z.
+// Z gains one column per new row (a multi right-hand-side solve with MFMA tiles), G one row and column;
+// the (<= WB_MAX)^2 system is solved in LDS.  Same linear system as the reference's updated factor.
+static const int WB_MAX = 128;
+static const double WB_MIN_PIVOT = 1e-2;      // smallest |pivot| of I + W G accepted (two digits of cancellation)
+// forward step kb for nr (multiple of 16) right-hand sides X (ld x nr): Z_kb = L_kk^-1 X_kb, X_i -= L(i,kb) Z_kb
+__global__ __launch_bounds__(256) void k_ldl_fwd_mr(const double *__restrict__ K, int ld, int kb, const double *__restrict__ Linv,
+                                                    double *__restrict__ X, double *__restrict__ Zo, int nr, int nb) {
+    extern __shared__ double smr[];
+    double *As = smr;                    // [k][row], stride 80
+    double *Bs = smr + DNB * 80;         // [col][k], stride 68 (X_kb, then Z_kb)
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
+    const int r64 = tid & 63, q4 = tid >> 6;
+    const int ng = nr >> 4;
+    const int g0 = wave, g1 = wave + 4;
+    const bool v0 = g0 < ng, v1 = g1 < ng;
+    const double *Li = Linv + (size_t)kb * DNB * DNB;
+    for (int e = 0; e < DNB / 4; e++) { const int k = q4 + 4 * e; As[k * 80 + r64] = Li[(size_t)k * DNB + r64]; }
+    for (int c = q4; c < nr; c += 4) Bs[c * 68 + r64] = X[(size_t)kb * DNB + r64 + (size_t)c * ld];
+    __syncthreads();
+    dvec4 acc[4][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int m = 0; m < 4; m++) { acc[m][0] = (dvec4){0.0, 0.0, 0.0, 0.0}; acc[m][1] = (dvec4){0.0, 0.0, 0.0, 0.0}; }
+    };
+    auto gemm = [&]() {
+#pragma unroll 4
+        for (int k0 = 0; k0 < DNB; k0 += 4) {
+            double a[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) a[m] = As[(k0 + lk) * 80 + m * 16 + li];
+            if (v0) {
+                const double b = Bs[(g0 * 16 + li) * 68 + k0 + lk];
+#pragma unroll
+                for (int m = 0; m < 4; m++) acc[m][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b, acc[m][0], 0, 0, 0);
+            }
+            if (v1) {
+                const double b = Bs[(g1 * 16 + li) * 68 + k0 + lk];
+#pragma unroll
+                for (int m = 0; m < 4; m++) acc[m][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b, acc[m][1], 0, 0, 0);
+            }
+        }
+    };
+    zero(); gemm();
+    __syncthreads();
+    // Z_kb replaces X_kb in LDS
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            if (v0) Bs[(g0 * 16 + li) * 68 + m * 16 + lk + 4 * v] = acc[m][0][v];
+            if (v1) Bs[(g1 * 16 + li) * 68 + m * 16 + lk + 4 * v] = acc[m][1][v];
+        }
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int c = q4; c < nr; c += 4) Zo[(size_t)kb * DNB + r64 + (size_t)c * ld] = Bs[c * 68 + r64];
+    const int ib = kb + 1 + blockIdx.x;
+    if (ib >= nb) return;
+    for (int e = 0; e < DNB / 4; e++) { const int k = q4 + 4 * e; As[k * 80 + r64] = K[(size_t)ib * DNB + r64 + ((size_t)kb * DNB + k) * ld]; }
+    __syncthreads();
+    zero(); gemm();
+    __syncthreads();
+    double *Cs = smr;                    // [col][row], stride 65, over As and Bs
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            if (v0) Cs[(g0 * 16 + li) * 65 + m * 16 + lk + 4 * v] = acc[m][0][v];
+            if (v1) Cs[(g1 * 16 + li) * 65 + m * 16 + lk + 4 * v] = acc[m][1][v];
+        }
+    __syncthreads();
+    for (int c = q4; c < nr; c += 4) { double *xp = X + (size_t)ib * DNB + r64 + (size_t)c * ld; *xp = *xp - Cs[c * 65 + r64]; }
+}
+// backward step kb: X_kb = L_kk^-T Y_kb, Y_j -= L(kb,j)' X_kb for j < kb
+__global__ __launch_bounds__(256) void k_ldl_bwd_mr(const double *__restrict__ K, int ld, int kb, const double *__restrict__ Linv,
+                                                    double *__restrict__ Y, double *__restrict__ Xo, int nr) {
+    extern __shared__ double smr[];
+    double *As = smr;                    // [row = column c of the tile][k = row r of the tile], stride 68
+    double *Bs = smr + DNB * 68;         // [col][k], stride 68
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
+    const int r64 = tid & 63, q4 = tid >> 6;
+    const int ng = nr >> 4;
+    const int g0 = wave, g1 = wave + 4;
+    const bool v0 = g0 < ng, v1 = g1 < ng;
+    const double *Li = Linv + (size_t)kb * DNB * DNB;
+    for (int e = 0; e < DNB / 4; e++) { const int c = q4 + 4 * e; As[c * 68 + r64] = Li[(size_t)c * DNB + r64]; }
+    for (int c = q4; c < nr; c += 4) Bs[c * 68 + r64] = Y[(size_t)kb * DNB + r64 + (size_t)c * ld];
+    __syncthreads();
+    dvec4 acc[4][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int m = 0; m < 4; m++) { acc[m][0] = (dvec4){0.0, 0.0, 0.0, 0.0}; acc[m][1] = (dvec4){0.0, 0.0, 0.0, 0.0}; }
+    };
+    auto gemm = [&]() {
+#pragma unroll 4
+        for (int k0 = 0; k0 < DNB; k0 += 4) {
+            double a[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) a[m] = As[(m * 16 + li) * 68 + k0 + lk];
+            if (v0) {
+                const double b = Bs[(g0 * 16 + li) * 68 + k0 + lk];
+#pragma unroll
+                for (int m = 0; m < 4; m++) acc[m][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b, acc[m][0], 0, 0, 0);
+            }
+            if (v1) {
+                const double b = Bs[(g1 * 16 + li) * 68 + k0 + lk];
+#pragma unroll
+                for (int m = 0; m < 4; m++) acc[m][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b, acc[m][1], 0, 0, 0);
+            }
+        }
+    };
+    zero(); gemm();
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            if (v0) Bs[(g0 * 16 + li) * 68 + m * 16 + lk + 4 * v] = acc[m][0][v];
+            if (v1) Bs[(g1 * 16 + li) * 68 + m * 16 + lk + 4 * v] = acc[m][1][v];
+        }
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int c = q4; c < nr; c += 4) Xo[(size_t)kb * DNB + r64 + (size_t)c * ld] = Bs[c * 68 + r64];
+    const int j = blockIdx.x;
+    if (kb == 0 || j >= kb) return;
+    for (int e = 0; e < DNB / 4; e++) { const int c = q4 + 4 * e; As[c * 68 + r64] = K[(size_t)kb * DNB + r64 + ((size_t)j * DNB + c) * ld]; }
+    __syncthreads();
+    zero(); gemm();
+    __syncthreads();
+    double *Cs = smr;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            if (v0) Cs[(g0 * 16 + li) * 65 + m * 16 + lk + 4 * v] = acc[m][0][v];
+            if (v1) Cs[(g1 * 16 + li) * 65 + m * 16 + lk + 4 * v] = acc[m][1][v];
+        }
+    __syncthreads();
+    for (int c = q4; c < nr; c += 4) { double *yp = Y + (size_t)j * DNB + r64 + (size_t)c * ld; *yp = *yp - Cs[c * 65 + r64]; }
+}
+__global__ void k_scale_d_mr(int ld, int nr, const double *__restrict__ Dg, double *__restrict__ Z) {
+    const size_t tot = (size_t)ld * nr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) Z[i] = Z[i] / Dg[i % ld];
+}
+// rows whose weight moved since the factorization and that hold no slot yet get the next slots, in row order
+__global__ __launch_bounds__(1024) void k_wb_select(int m, const double *__restrict__ dw, const double *__restrict__ dfact, int *__restrict__ slot,
+                                                    int *__restrict__ rows, int k_old, int *__restrict__ cnt) {
+    __shared__ int sums[1024];
+    const int chunk = (m + 1023) / 1024;
+    const int beg = threadIdx.x * chunk, end = min(beg + chunk, m);
+    int c = 0;
+    for (int i = beg; i < end; i++) c += (dw[i] != dfact[i] && slot[i] < 0);
+    sums[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; i++) { int t = sums[i]; sums[i] = run; run += t; } cnt[0] = k_old + run; }
+    __syncthreads();
+    int pos = k_old + sums[threadIdx.x];
+    for (int i = beg; i < end; i++)
+        if (dw[i] != dfact[i] && slot[i] < 0) { if (pos < WB_MAX) { rows[pos] = i; slot[i] = pos; } pos++; }
+}
+// right-hand side columns: X(:, k_old + b) = row rows[k_old + b] of A as a dense vector (zero for the padding columns)
+__global__ __launch_bounds__(256) void k_wb_rhs(int ld, int k_old, int k_new, const int *__restrict__ rows, const int *__restrict__ arp,
+                                                const int *__restrict__ aci, const double *__restrict__ aval, double *__restrict__ X) {
+    double *col = X + (size_t)(k_old + blockIdx.x) * ld;
+    for (int i = threadIdx.x; i < ld; i += blockDim.x) col[i] = 0.0;
+    __syncthreads();
+    if ((int)blockIdx.x >= k_new) return;
+    const int r = rows[k_old + blockIdx.x];
+    for (int e = arp[r] + threadIdx.x; e < arp[r + 1]; e += blockDim.x) col[aci[e]] = aval[e];
+}
+// G(a,b) = A(rows[a],:) Z(:,b) for the new columns b (and, by symmetry, the new rows)
+__global__ __launch_bounds__(64) void k_wb_G(int k_old, const int *__restrict__ rows, const int *__restrict__ arp, const int *__restrict__ aci,
+                                             const double *__restrict__ aval, const double *__restrict__ Z, int ld, double *__restrict__ G) {
+    const int a = blockIdx.x, b = k_old + blockIdx.y;
+    if (a > b) return;
+    const int r = rows[a];
+    const double *zc = Z + (size_t)b * ld;
+    double sacc = 0.0;
+    for (int e = arp[r] + threadIdx.x; e < arp[r + 1]; e += 64) sacc += aval[e] * zc[aci[e]];
+    sacc = wave_sum(sacc);
+    if (threadIdx.x == 0) { G[a * WB_MAX + b] = sacc; G[b * WB_MAX + a] = sacc; }
+}
+// v_a = A(rows[a],:) z0,  w_a = d - d_fact at that row
+__global__ __launch_bounds__(64) void k_wb_v(const int *__restrict__ rows, const int *__restrict__ arp, const int *__restrict__ aci,
+                                             const double *__restrict__ aval, const double *__restrict__ z0, const double *__restrict__ dw,
+                                             const double *__restrict__ dfact, double *__restrict__ v, double *__restrict__ w) {
+    const int a = blockIdx.x, r = rows[a];
+    double sacc = 0.0;
+    for (int e = arp[r] + threadIdx.x; e < arp[r + 1]; e += 64) sacc += aval[e] * z0[aci[e]];
+    sacc = wave_sum(sacc);
+    if (threadIdx.x == 0) { v[a] = sacc; w[a] = dw[r] - dfact[r]; }
+}
+// t = (I + W G)^-1 W v by Gauss-Jordan elimination with partial pivoting, all in LDS (k <= WB_MAX)
+__global__ __launch_bounds__(1024) void k_wb_lu(int k, const double *__restrict__ G, const double *__restrict__ w, const double *__restrict__ v,
+                                                double *__restrict__ t) {
+    extern __shared__ double smr[];
+    const int S = k + 2;                                  // row stride: k columns + right-hand side (+1 keeps it even/odd mixed)
+    double *M = smr;
+    __shared__ double red_v[16]; __shared__ int red_i[16]; __shared__ int piv_s; __shared__ double piv_inv, piv_min;
+    const int tid = threadIdx.x;
+    if (tid == 0) piv_min = 1.0;
+    for (int e = tid; e < k * (k + 1); e += 1024) {
+        const int a = e / (k + 1), b = e % (k + 1);
+        M[a * S + b] = b < k ? ((a == b ? 1.0 : 0.0) + w[a] * G[a * WB_MAX + b]) : w[a] * v[a];
+    }
+    __syncthreads();
+    for (int j = 0; j < k; j++) {
+        // pivot: largest |M[r][j]|, r >= j (ties -> smallest r)
+        double best = -1.0; int bi = j;
+        for (int r = j + tid; r < k; r += 1024) { const double x = fabs(M[r * S + j]); if (x > best) { best = x; bi = r; } }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_down(best, off); const int oi = __shfl_down(bi, off);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if ((tid & 63) == 0) { red_v[tid >> 6] = best; red_i[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double bb = red_v[0]; int ii = red_i[0];
+            for (int q = 1; q < 16; q++) if (red_v[q] > bb || (red_v[q] == bb && red_i[q] < ii)) { bb = red_v[q]; ii = red_i[q]; }
+            piv_s = ii; piv_inv = 1.0 / M[ii * S + j];
+            if (!(bb >= piv_min)) piv_min = bb;            // NaN-propagating minimum of |pivot|
+        }
+        __syncthreads();
+        const int p = piv_s; const double pinv = piv_inv;
+        if (p != j) for (int c = j + tid; c <= k; c += 1024) { const double x = M[j * S + c]; M[j * S + c] = M[p * S + c]; M[p * S + c] = x; }
+        __syncthreads();
+        // eliminate column j from every other row; columns j+1..k (k = right-hand side)
+        const int ncol = k - j;                            // columns j+1 .. k
+        for (int e = tid; e < k * ncol; e += 1024) {
+            const int r = e / ncol, c = j + 1 + e % ncol;
+            if (r != j) M[r * S + c] -= (M[r * S + j] * pinv) * M[j * S + c];
+        }
+        __syncthreads();
+        for (int c = j + 1 + tid; c <= k; c += 1024) M[j * S + c] *= pinv;
+        __syncthreads();
+    }
+    for (int a = tid; a < k; a += 1024) t[a] = M[a * S + k];
+    if (tid == 0) t[WB_MAX] = piv_min;                     // M = I at k = 0 weight change: pivots near 1 mean a benign update
+}
+// dx = z0 - Z t
+__global__ void k_wb_apply(int n, int ld, int k, const double *__restrict__ Z, const double *__restrict__ t, const double *__restrict__ z0,
+                           double *__restrict__ dx) {
+    __shared__ double ts[WB_MAX];
+    for (int a = threadIdx.x; a < k; a += blockDim.x) ts[a] = t[a];
+    __syncthreads();
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        double sacc = 0.0;
+        for (int a = 0; a < k; a++) sacc += Z[(size_t)a * ld + j] * ts[a];
+        dx[j] = z0[j] - sacc;
+    }
 }
 __global__ void k_dense_load_rhs(int n, int ld, const double *__restrict__ b, double *__restrict__ x) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ld; i += gridDim.x * blockDim.x) x[i] = i < n ? b[i] : 0.0;
@@ -2003,6 +2301,8 @@ void qdev_destroy(QpdoDev *d) {
     if (d->comm.nccl) ncclCommDestroy(d->comm.nccl);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
+    for (int i = 0; i < 2; i++) { if (d->evF[i]) (void)hipEventDestroy(d->evF[i]); if (d->evB[i]) (void)hipEventDestroy(d->evB[i]); }
+    if (d->stream2) (void)hipStreamDestroy(d->stream2);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -2013,6 +2313,8 @@ int qdev_configure(QpdoDev *d, int linsolve, double pcg_tol, int pcg_maxit) {
     if (gr && !strcmp(gr, "0")) d->pcg_graph = 0;
     const char *mx = getenv("QPDO_DENSE_MAX_N");
     if (mx && *mx) d->dense_max_n = atoi(mx);
+    const char *lr = getenv("QPDO_DENSE_LOWRANK");
+    if (lr && !strcmp(lr, "0")) d->wb_enable = 0;
     if (d->dense_max_n > 18000) d->dense_max_n = 18000;       // the assembly accumulator (n doubles) must fit in LDS
     if (linsolve >= 0) d->linsolve = linsolve;
     else d->linsolve = (d->n <= d->dense_max_n) ? 1 : 0;
@@ -2058,7 +2360,7 @@ int qdev_scale_data(QpdoDev *d, int iters, int use_Qx, double *D_host, double *E
     const int gQ = spmv_grid(d->Qf, d->Qf.tpr, false);
     DISPATCH_TPR(d->Qf, k_scale_sym, gQ, n, d->Qf.rp, d->Qf.ci, d->Qf.val, (const double *)d->D);
     if (d->comm.world > 1 && d->Qs.nnz) hipLaunchKernelGGL(k_scale_sym_rows, dim3(vgrid(d->nloc)), dim3(BLK), 0, d->stream, d->nloc, d->n0, d->Qs.rp, d->Qs.ci, d->Qs.val, (const double *)d->D);
-    d->qdiag_valid = 0; d->dense_valid = 0;
+    d->qdiag_valid = 0; d->dense_valid = 0; d->dense_factored = 0;
     LAUNCH(k_mul, vgrid(n), n, d->D, d->q, d->q);                    // q <- D q
     // cost scaling: c = 1 / max(1, ||Qx + q||inf)
     LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
@@ -2113,7 +2415,7 @@ int qdev_download_q(QpdoDev *d, double *q) {
 }
 int qdev_scale_Q_values(QpdoDev *d, double factor) {
     HIPCHK(hipSetDevice(d->device));
-    d->qdiag_valid = 0; d->dense_valid = 0;
+    d->qdiag_valid = 0; d->dense_valid = 0; d->dense_factored = 0;
     if (d->comm.world > 1 && d->Qs.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qs.nnz, d->Qs.val, factor);
     if (d->Qf.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qf.nnz, d->Qf.val, factor);
     HIPCHK(hipGetLastError());
@@ -2292,6 +2594,8 @@ static int defl_build(QpdoDev *d) {
     int rc = read_ctrl(d); if (rc) return rc;
     const double dmax = nrm_of(d->hctrl, N_A);
     if (!(dmax > 0.0)) return 0;
+    static const bool dbg = getenv("QPDO_DEFL_DEBUG") != nullptr;
+    if (dbg) { fprintf(stderr, "[defl] k=%d dmax=%.3e sigma_f=%.3e hist:", k, dmax, d->sigma_f); for (int b = 0; b < 32; b++) fprintf(stderr, " %d", hist[b]); fprintf(stderr, "\n"); }
     // largest bucket index kb whose cumulative count still fits; rows in buckets 0..kb are > dmax / 2^(kb+1)
     int cum = 0, kb = -1;
     for (int b = 0; b < 32; b++) { if (cum + hist[b] > DEFL_MAX) break; cum += hist[b]; kb = b; }
@@ -2467,6 +2771,7 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
     if (graph) (void)hipGraphDestroy(graph);
     if (rc) return rc;
     *iters_out = d->hctrl->cnt[C_PCG_IT];
+    if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[pcg] k=%d defl_r=%d iters=%d\n", k, d->defl_r, *iters_out);
     return 0;
 }
 
@@ -2477,9 +2782,47 @@ static int dense_alloc(QpdoDev *d) {
     const int ld = (d->n + DNB - 1) / DNB * DNB;
     d->dense_ld = ld; d->dense_nblk = ld / DNB;
     int rc = dev_alloc(d, &d->Kd, (size_t)ld * ld);
-    if (!rc) rc = dev_alloc(d, &d->Wd, (size_t)ld * DNB * DOUTER);
+    if (!rc) rc = dev_alloc(d, &d->Wd, (size_t)2 * ld * DNB * DOUTER);     // two outer panels of W = L D (look-ahead)
+    if (!rc && !d->stream2) {
+        // The trailing updates would fill every CU and starve the one-workgroup diagonal kernel of the next panel
+        // (it needs 66 KB of LDS on one CU), so their stream leaves a few CUs out of its mask.
+        int reserve = 32;
+        if (const char *rs = getenv("QPDO_DENSE_RESERVE_CUS")) reserve = atoi(rs);
+        hipDeviceProp_t prop; int ncu = 256;
+        if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        hipError_t e = hipErrorInvalidValue;
+        if (reserve > 0 && reserve < ncu) {
+            const int words = (ncu + 31) / 32;
+            std::vector<uint32_t> mask((size_t)words, 0u);
+            for (int c = 0; c < ncu - reserve; c++) mask[c >> 5] |= 1u << (c & 31);
+            e = hipExtStreamCreateWithCUMask(&d->stream2, (uint32_t)words, mask.data());
+            if (e != hipSuccess) { (void)hipGetLastError(); d->stream2 = nullptr; }
+        }
+        if (e != hipSuccess) e = hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && e == hipSuccess; i++) { e = hipEventCreateWithFlags(&d->evF[i], hipEventDisableTiming); if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evB[i], hipEventDisableTiming); }
+        if (e != hipSuccess) rc = set_err(e, "dense look-ahead stream", __LINE__);
+    }
     if (!rc) rc = dev_alloc(d, &d->Dg, (size_t)ld);
     if (!rc) rc = dev_alloc(d, &d->Linv, (size_t)d->dense_nblk * DNB * DNB);
+    if (!rc && d->wb_enable) {
+        const size_t mm = d->m > 0 ? (size_t)d->m : 1;
+        rc = dev_alloc(d, &d->d_fact, mm);
+        if (!rc) rc = dev_alloc(d, &d->wb_Z, (size_t)ld * (WB_MAX + 16));      // + one padding group of right-hand sides
+        if (!rc) rc = dev_alloc(d, &d->wb_T, (size_t)ld * (WB_MAX + 16));
+        if (!rc) rc = dev_alloc(d, &d->wb_G, (size_t)WB_MAX * WB_MAX);
+        if (!rc) rc = dev_alloc(d, &d->wb_v, (size_t)WB_MAX);
+        if (!rc) rc = dev_alloc(d, &d->wb_w, (size_t)WB_MAX);
+        if (!rc) rc = dev_alloc(d, &d->wb_t, (size_t)WB_MAX + 1);
+        if (!rc) rc = dev_alloc(d, &d->wb_slot, mm);
+        if (!rc) rc = dev_alloc(d, &d->wb_rows, (size_t)WB_MAX);
+        if (!rc) rc = dev_alloc(d, &d->wb_cnt, (size_t)2);
+        if (!rc) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldl_fwd_mr), hipFuncAttributeMaxDynamicSharedMemorySize, (DNB * 80 + WB_MAX * 68) * 8);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldl_bwd_mr), hipFuncAttributeMaxDynamicSharedMemorySize, (DNB * 68 + WB_MAX * 68) * 8);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wb_lu), hipFuncAttributeMaxDynamicSharedMemorySize, WB_MAX * (WB_MAX + 2) * 8);
+            if (e != hipSuccess) rc = set_err(e, "hipFuncSetAttribute", __LINE__);
+        }
+    }
     if (!rc) rc = dev_alloc(d, &d->dz, (size_t)ld);
     if (!rc) rc = dev_alloc(d, &d->dxw, (size_t)ld);
     if (!rc) {
@@ -2493,33 +2836,64 @@ static int dense_factor(QpdoDev *d) {
     const int n = d->n, ld = d->dense_ld, nb = d->dense_nblk;
     const int g = ld < 1024 ? ld : 1024;
     static const bool kc16 = [] { const char *e = getenv("QPDO_SYRK_KC"); return !(e && atoi(e) == 32); }();
+    static const bool diag1 = [] { const char *e = getenv("QPDO_DENSE_DIAG"); return !(e && atoi(e) == 16); }();
+    static const bool lookahead = [] { const char *e = getenv("QPDO_DENSE_LOOKAHEAD"); return !(e && atoi(e) == 0); }();
     hipLaunchKernelGGL(k_dense_assemble, dim3(g), dim3(64), (size_t)n * sizeof(double), d->stream, n, ld, d->Qf.rp, d->Qf.ci, d->Qf.val,
                        d->At.rp, d->At.ci, d->At.val, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)d->d, d->sigma_f, d->Kd);
-    for (int J0 = 0; J0 < nb; J0 += DOUTER) {
+    // Outer panel p (DOUTER block columns): F_p = its factorization (a serial diag -> panel -> narrow update chain that
+    // fills few CUs), a_p = trailing update of the NEXT outer panel's columns, b_p = trailing update of everything
+    // beyond.  One-deep look-ahead: F_p, a_p on the main stream, b_p on stream2, so that F_{p+1} overlaps b_p.
+    //   F_p <- a_{p-1};  a_p, b_p <- F_p, b_{p-1};  W_p lives in buffer p&1 (F_{p+1} <- a_p <- b_{p-1}: its reader is done).
+    // Every element of K receives the same updates in the same order as without look-ahead: results are bit-identical.
+    auto syrk = [&](hipStream_t st, const double *W, int kb0, int nkb, int wcol0, int tj_lo, int tj_hi) {
+        const dim3 grid(nb - tj_lo, tj_hi - tj_lo);
+        if (kc16) hipLaunchKernelGGL(k_ldl_syrk<16>, grid, dim3(256), 0, st, d->Kd, ld, W, kb0, nkb, wcol0, tj_lo, tj_hi);
+        else      hipLaunchKernelGGL(k_ldl_syrk<32>, grid, dim3(256), 0, st, d->Kd, ld, W, kb0, nkb, wcol0, tj_lo, tj_hi);
+    };
+    bool b_pending = false;
+    int p = 0;
+    for (int J0 = 0; J0 < nb; J0 += DOUTER, p++) {
         const int Jend = J0 + DOUTER < nb ? J0 + DOUTER : nb;
+        double *W = d->Wd + (size_t)(p & 1) * ld * DNB * DOUTER;
         for (int kb = J0; kb < Jend; kb++) {
-            hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(1024), 0, d->stream, d->Kd, ld, kb, d->Dg, d->Linv);
+            if (diag1) hipLaunchKernelGGL(k_ldl_diag1, dim3(1), dim3(128), 0, d->stream, d->Kd, ld, kb, d->Dg, d->Linv);
+            else       hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(1024), 0, d->stream, d->Kd, ld, kb, d->Dg, d->Linv);
             const int below = nb - kb - 1;
             if (below > 0) {
                 hipLaunchKernelGGL(k_ldl_panel, dim3(below), dim3(256), 0, d->stream, d->Kd, ld, kb, kb - J0, (const double *)d->Dg,
-                                   (const double *)d->Linv, d->Wd);
-                if (kb + 1 < Jend) {    // rest of this outer panel
-                    if (kc16) hipLaunchKernelGGL(k_ldl_syrk<16>, dim3(nb - (kb + 1), Jend - (kb + 1)), dim3(256), 0, d->stream, d->Kd, ld, (const double *)d->Wd, kb, 1, kb - J0, kb + 1, Jend);
-                    else      hipLaunchKernelGGL(k_ldl_syrk<32>, dim3(nb - (kb + 1), Jend - (kb + 1)), dim3(256), 0, d->stream, d->Kd, ld, (const double *)d->Wd, kb, 1, kb - J0, kb + 1, Jend);
-                }
+                                   (const double *)d->Linv, W);
+                if (kb + 1 < Jend) syrk(d->stream, W, kb, 1, kb - J0, kb + 1, Jend);      // rest of this outer panel
             }
         }
-        if (Jend < nb) {                // trailing matrix: all columns of the outer panel at once
-            if (kc16) hipLaunchKernelGGL(k_ldl_syrk<16>, dim3(nb - Jend, nb - Jend), dim3(256), 0, d->stream, d->Kd, ld, (const double *)d->Wd, J0, Jend - J0, 0, Jend, nb);
-            else      hipLaunchKernelGGL(k_ldl_syrk<32>, dim3(nb - Jend, nb - Jend), dim3(256), 0, d->stream, d->Kd, ld, (const double *)d->Wd, J0, Jend - J0, 0, Jend, nb);
+        if (Jend < nb) {
+            const int Jend2 = (lookahead && Jend + DOUTER < nb) ? Jend + DOUTER : nb;
+            if (Jend2 < nb) {
+                HIPCHK(hipEventRecord(d->evF[p & 1], d->stream));
+                HIPCHK(hipStreamWaitEvent(d->stream2, d->evF[p & 1], 0));
+            }
+            if (b_pending) HIPCHK(hipStreamWaitEvent(d->stream, d->evB[(p - 1) & 1], 0));
+            b_pending = false;
+            syrk(d->stream, W, J0, Jend - J0, 0, Jend, Jend2);                             // a_p
+            if (Jend2 < nb) {
+                syrk(d->stream2, W, J0, Jend - J0, 0, Jend2, nb);                          // b_p
+                HIPCHK(hipEventRecord(d->evB[p & 1], d->stream2));
+                b_pending = true;
+            }
         }
     }
+    if (b_pending) HIPCHK(hipStreamWaitEvent(d->stream, d->evB[(p - 1) & 1], 0));
     HIPCHK(hipGetLastError());
     d->dense_valid = 1;
+    d->dense_factored = 1; d->dense_fact_sigma = d->sigma_f; d->wb_k = 0;
+    if (d->wb_enable && d->m > 0) {        // the factor belongs to this weight vector; no row holds a low-rank slot
+        HIPCHK(hipMemcpyAsync(d->d_fact, d->d, (size_t)d->m * 8, hipMemcpyDeviceToDevice, d->stream));
+        HIPCHK(hipMemsetAsync(d->wb_slot, 0xFF, (size_t)d->m * sizeof(int), d->stream));
+    }
     d->st.factor_count++;
     return 0;
 }
-static int dense_solve(QpdoDev *d) {
+// z0 = K0^-1 rhs into dxw (ld entries)
+static int dense_solve_core(QpdoDev *d) {
     const int n = d->n, ld = d->dense_ld, nb = d->dense_nblk;
     LAUNCH(k_dense_load_rhs, vgrid(ld), n, ld, (const double *)d->rhs, d->dxw);
     for (int kb = 0; kb < nb; kb++) {
@@ -2529,7 +2903,67 @@ static int dense_solve(QpdoDev *d) {
     LAUNCH(k_dense_scale_d, vgrid(ld), ld, (const double *)d->dz, (const double *)d->Dg, d->dz);
     for (int kb = nb - 1; kb >= 0; kb--)
         hipLaunchKernelGGL(k_ldl_bwd, dim3(kb > 0 ? kb : 1), dim3(64), 0, d->stream, (const double *)d->Kd, ld, kb, (const double *)d->Linv, d->dz, d->dxw);
-    HIPCHK(hipMemcpyAsync(d->dx, d->dxw, (size_t)n * 8, hipMemcpyDeviceToDevice, d->stream));
+    return 0;
+}
+static int dense_solve(QpdoDev *d) {
+    int rc = dense_solve_core(d); if (rc) return rc;
+    const int n = d->n, ld = d->dense_ld, k = d->wb_k;
+    if (k == 0) {
+        HIPCHK(hipMemcpyAsync(d->dx, d->dxw, (size_t)n * 8, hipMemcpyDeviceToDevice, d->stream));
+        return 0;
+    }
+    // low-rank correction: dx = z0 - Z (I + W G)^-1 W U z0
+    hipLaunchKernelGGL(k_wb_v, dim3(k), dim3(64), 0, d->stream, (const int *)d->wb_rows, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)d->dxw,
+                       (const double *)d->d, (const double *)d->d_fact, d->wb_v, d->wb_w);
+    hipLaunchKernelGGL(k_wb_lu, dim3(1), dim3(1024), (size_t)k * (k + 2) * 8, d->stream, k, (const double *)d->wb_G, (const double *)d->wb_w,
+                       (const double *)d->wb_v, d->wb_t);
+    // A downdate that removes most of a direction of K0 (pivot -> 0) loses that many digits in the correction:
+    // refactor with the current weights instead, as a full factorization would have been exact there.
+    double minpiv = 0.0;
+    HIPCHK(hipMemcpyAsync(&minpiv, d->wb_t + WB_MAX, sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (!(minpiv >= WB_MIN_PIVOT)) {
+        d->st.lowrank_rejects++;
+        rc = dense_factor(d); if (rc) return rc;
+        rc = dense_solve_core(d); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(d->dx, d->dxw, (size_t)n * 8, hipMemcpyDeviceToDevice, d->stream));
+        return 0;
+    }
+    LAUNCH(k_wb_apply, vgrid(n), n, ld, k, (const double *)d->wb_Z, (const double *)d->wb_t, (const double *)d->dxw, d->dx);
+    HIPCHK(hipGetLastError());
+    d->st.lowrank_solves++;
+    return 0;
+}
+// Give every row whose weight differs from the factored one a low-rank slot; new slots get their column of
+// Z = K0^-1 U' (multi right-hand-side MFMA block solve) and their row and column of G.  *overflow = 1: more
+// than WB_MAX rows differ, the caller refactors.
+static int wb_extend(QpdoDev *d, int *overflow) {
+    const int ld = d->dense_ld, nb = d->dense_nblk, k_old = d->wb_k;
+    *overflow = 0;
+    hipLaunchKernelGGL(k_wb_select, dim3(1), dim3(1024), 0, d->stream, d->m, (const double *)d->d, (const double *)d->d_fact, d->wb_slot, d->wb_rows,
+                       k_old, d->wb_cnt);
+    int cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, d->wb_cnt, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (cnt > WB_MAX) { *overflow = 1; return 0; }
+    const int k_new = cnt - k_old;
+    if (k_new <= 0) return 0;
+    const int nr = (k_new + 15) / 16 * 16;                 // padding columns are zero right-hand sides (buffers hold WB_MAX + 16)
+    double *X = d->wb_Z + (size_t)k_old * ld, *T = d->wb_T + (size_t)k_old * ld;
+    hipLaunchKernelGGL(k_wb_rhs, dim3(nr), dim3(256), 0, d->stream, ld, k_old, k_new, (const int *)d->wb_rows, d->Ar.rp, d->Ar.ci, d->Ar.val, d->wb_Z);
+    const size_t lds_f = (size_t)(DNB * 80 + nr * 68) * 8, lds_b = (size_t)(DNB * 68 + nr * 68) * 8;
+    for (int kb = 0; kb < nb; kb++) {
+        const int below = nb - kb - 1;
+        hipLaunchKernelGGL(k_ldl_fwd_mr, dim3(below > 0 ? below : 1), dim3(256), lds_f, d->stream, (const double *)d->Kd, ld, kb, (const double *)d->Linv, X, T, nr, nb);
+    }
+    LAUNCH(k_scale_d_mr, vgrid(ld) * 4, ld, nr, (const double *)d->Dg, T);
+    for (int kb = nb - 1; kb >= 0; kb--)
+        hipLaunchKernelGGL(k_ldl_bwd_mr, dim3(kb > 0 ? kb : 1), dim3(256), lds_b, d->stream, (const double *)d->Kd, ld, kb, (const double *)d->Linv, T, X, nr);
+    hipLaunchKernelGGL(k_wb_G, dim3(cnt, k_new), dim3(64), 0, d->stream, k_old, (const int *)d->wb_rows, d->Ar.rp, d->Ar.ci, d->Ar.val,
+                       (const double *)d->wb_Z, ld, d->wb_G);
+    HIPCHK(hipGetLastError());
+    d->wb_k = cnt;
+    d->st.lowrank_cols += k_new;
     return 0;
 }
 
@@ -2569,7 +3003,16 @@ int qdev_newton_step(QpdoDev *d, int branch, int n_changed, int proximal, double
     else if (branch == 1) { if (n_changed > 0) d->dense_valid = 0; }
     else if (!(d->dense_last_branch == 2 && d->dense_last_sigma == d->sigma_f)) d->dense_valid = 0;
     if (d->linsolve == 1) {
-        if (!d->dense_valid) { rc = dense_factor(d); if (rc) return rc; }
+        if (!d->dense_valid) {
+            // reference: full factorization in branch 0, rank update of the kept factor otherwise (newton.c:21-33)
+            bool full = !d->dense_factored || branch == 0 || !d->wb_enable || d->sigma_f != d->dense_fact_sigma;
+            if (!full) {
+                int overflow = 0;
+                rc = wb_extend(d, &overflow); if (rc) return rc;
+                if (overflow) full = true; else d->dense_valid = 1;
+            }
+            if (full) { rc = dense_factor(d); if (rc) return rc; }
+        }
         rc = dense_solve(d); if (rc) return rc;
     } else {
         rc = pcg_solve(d, &lin); if (rc) return rc;
