@@ -46,7 +46,7 @@ static int set_err(hipError_t e, const char *what, int line) {
 // control block: everything the host reads back per pass
 // ------------------------------------------------------------------------------------------------
 enum { N_PRIM = 0, N_DUAL, N_PRIM_IN, N_DUAL_IN, N_A, N_B, N_C, N_D, N_COUNT };
-enum { C_ACTIVE = 0, C_ENTER, C_LEAVE, C_NL, C_KSTAR, C_MUCH, C_VIOL, C_PCG_DONE, C_PCG_IT, C_COUNT = 12 };
+enum { C_ACTIVE = 0, C_ENTER, C_LEAVE, C_NL, C_KSTAR, C_MUCH, C_VIOL, C_PCG_DONE, C_PCG_IT, C_CHAIN_ERR, C_COUNT = 12 };
 enum { V_TAU = 0, V_A0, V_B0, V_RZ, V_BNORM, V_OOB, V_QDX, V_OBJ, V_F, V_RR, V_COUNT = 16 };
 struct Ctrl {
     u64 nrm[N_COUNT];      // non-negative doubles as bit patterns: atomicMax is exact and order free
@@ -99,11 +99,12 @@ struct QpdoDev {
     double *defl_flag = nullptr, *defl_t = nullptr, *defl_S = nullptr, *defl_Sinv = nullptr, *defl_v = nullptr; long long defl_passes = 0;
     // dense direct solver
     int dense_ld = 0, dense_nblk = 0, dense_valid = 0;
-    int dense_max_n = 8192;   // measured crossover with deflated PCG: n ~ 8e3
-    double *Kd = nullptr, *Wd = nullptr, *Dg = nullptr, *Linv = nullptr, *dz = nullptr, *dxw = nullptr;
+    int dense_max_n = 12288;  // dense beats deflated PCG at n = 1e4 (0.90 s vs 1.35 s at C2)
+    double *Kd = nullptr, *Wd = nullptr, *Dg = nullptr, *Linv = nullptr, *LinvT = nullptr, *dz = nullptr, *dxw = nullptr;
+    double *ch_y = nullptr, *ch_x = nullptr, *dsol = nullptr; int dense_chain = 1;
     hipStream_t stream2 = nullptr;            // dense factor look-ahead: trailing updates run here
     // low-rank factor update (Woodbury on the kept factor): see the k_wb_* kernels
-    int dense_factored = 0, wb_enable = 1, wb_k = 0; double dense_fact_sigma = 0.0;
+    int dense_factored = 0, wb_enable = 0, wb_k = 0; double dense_fact_sigma = 0.0;
     double *d_fact = nullptr, *wb_Z = nullptr, *wb_T = nullptr, *wb_G = nullptr, *wb_v = nullptr, *wb_w = nullptr, *wb_t = nullptr;
     int *wb_slot = nullptr, *wb_rows = nullptr, *wb_cnt = nullptr;
     hipEvent_t evF[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr};
@@ -1508,68 +1509,18 @@ __device__ __forceinline__ void mfma_64x64x64(const double (*As)[80], const doub
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
 }
-// LDL' of the 64x64 diagonal block kb; writes unit-lower L back, D to Dg and the inverse of L
-// (column-major: Li[c*64 + r] = (L^-1)[r][c]) for the panel solve and the triangular solves.
-// Register-resident: thread (wave w, lane c) owns column c, rows w, w+16, w+32, w+48 of the block (a) and of the
-// running inverse (x, Gauss-Jordan: the row operations of step j applied to the identity).  Per elimination
-// step the owners publish pivot column j+1 and inverse row j+1 through double-buffered LDS: one barrier a step.
-#define DG_WAVES 16                       // 1024 threads: thread (wave w, lane c) owns column c, rows w, w+16, w+32, w+48
-#define DG_RPT (DNB / DG_WAVES)
-__global__ __launch_bounds__(1024) void k_ldl_diag(double *__restrict__ K, int ld, int kb, double *__restrict__ Dg, double *__restrict__ Linv) {
-    __shared__ double colv[2][DNB];
-    __shared__ double xrow[2][DNB];
-    const int tid = threadIdx.x;
-    const int c = tid & 63, w = tid >> 6;
-    const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
-    double a[DG_RPT], x[DG_RPT];
-#pragma unroll
-    for (int rr = 0; rr < DG_RPT; rr++) { a[rr] = K[base + (w + DG_WAVES * rr) + (size_t)c * ld]; x[rr] = (w + DG_WAVES * rr == c) ? 1.0 : 0.0; }
-    if (c == 0) {
-#pragma unroll
-        for (int rr = 0; rr < DG_RPT; rr++) colv[0][w + DG_WAVES * rr] = a[rr];
-    }
-    if (w == 0) xrow[0][c] = x[0];                                 // row 0 of the identity
-    __syncthreads();
-#pragma unroll 1
-    for (int j = 0; j < DNB; j++) {
-        const double *cv = colv[j & 1];
-        const double dj = cv[j], inv_dj = 1.0 / dj, xj = xrow[j & 1][c];
-        if (c > j) {                                               // a_ic -= v_i v_c / d_j  for j < c <= i
-            const double wc = cv[c] * inv_dj;
-#pragma unroll
-            for (int rr = 0; rr < DG_RPT; rr++) { const int i = w + DG_WAVES * rr; if (i >= c) a[rr] -= cv[i] * wc; }
-        } else if (c == j) {                                       // column j becomes L(:,j) = v * (1/d_j), diagonal keeps d_j
-#pragma unroll
-            for (int rr = 0; rr < DG_RPT; rr++) { const int i = w + DG_WAVES * rr; if (i > j) a[rr] = a[rr] * inv_dj; }
-        }
-#pragma unroll
-        for (int rr = 0; rr < DG_RPT; rr++) { const int i = w + DG_WAVES * rr; if (i > j) x[rr] -= (cv[i] * inv_dj) * xj; }   // X(i,:) -= l_ij X(j,:)
-        if (c == j + 1) {                                          // publish the next pivot column (already updated)
-#pragma unroll
-            for (int rr = 0; rr < DG_RPT; rr++) colv[(j + 1) & 1][w + DG_WAVES * rr] = a[rr];
-        }
-        if (w == ((j + 1) & (DG_WAVES - 1))) {                     // and row j+1 of the running inverse (final after this step)
-#pragma unroll
-            for (int rr = 0; rr < DG_RPT; rr++) if (w + DG_WAVES * rr == j + 1) xrow[(j + 1) & 1][c] = x[rr];
-        }
-        __syncthreads();
-    }
-    double *o = Linv + (size_t)kb * DNB * DNB;
-#pragma unroll
-    for (int rr = 0; rr < DG_RPT; rr++) {
-        const int i = w + DG_WAVES * rr;
-        if (i > c) K[base + i + (size_t)c * ld] = a[rr];
-        if (i == c) Dg[kb * DNB + c] = a[rr];
-        o[(size_t)c * DNB + i] = x[rr];
-    }
-}
-// Two-wave variant: lane i of wave 0 keeps row i of the block, lane i of wave 1 column i of the running inverse,
+// LDL' of the 64x64 diagonal block kb; writes unit-lower L back, D to Dg, the inverse of L
+// (column-major: Li[c*64 + r] = (L^-1)[r][c]) for the panel solve and the forward solves, and its transpose
+// (LiT[r*64 + c]) for the backward solves.
+// Two waves: lane i of wave 0 keeps row i of the block, lane i of wave 1 column i of the running inverse,
 // both as 64 registers (fully unrolled: every register index is a constant).  Step j: wave 0 publishes column j
 // through LDS, every lane reads it back as broadcasts and applies  r_c -= (r_j / d_j) v_c  for c > j -- for wave 0
 // that is a_ic -= l_ij v_c, for wave 1 the row operation X(c,i) -= l_cj X(j,i) of Gauss-Jordan on the identity.
-// A step costs one two-wave barrier and one LDS round trip instead of a 16-wave barrier.  The two roles differ
-// only by selects, never by branches around the register array (divergent copies of it spill).
-__global__ __launch_bounds__(128) void k_ldl_diag1(double *__restrict__ K, int ld, int kb, double *__restrict__ Dg, double *__restrict__ Linv) {
+// A step costs one two-wave barrier and one LDS round trip (28 us per block; a 1024-thread version with a
+// 16-wave barrier per step took 61 us).  The two roles differ only by selects, never by branches around the
+// register array (divergent copies of it spill).
+__global__ __launch_bounds__(128) void k_ldl_diag(double *__restrict__ K, int ld, int kb, double *__restrict__ Dg, double *__restrict__ Linv,
+                                                   double *__restrict__ LinvT) {
     __shared__ double colb[2][DNB];
     __shared__ double Ts[DNB][DNB + 1];
     const int i = threadIdx.x & 63;
@@ -1596,10 +1547,15 @@ __global__ __launch_bounds__(128) void k_ldl_diag1(double *__restrict__ K, int l
         if (!is_a) Ts[i][c] = r[c];
     }
     __syncthreads();
-    double *o = Linv + (size_t)kb * DNB * DNB;
-    for (int e = threadIdx.x; e < DNB * DNB; e += 128) { const int c = e >> 6, q = e & 63; o[(size_t)c * DNB + q] = Ts[c][q]; }
+    double *o = Linv + (size_t)kb * DNB * DNB, *ot = LinvT + (size_t)kb * DNB * DNB;
+    for (int e = threadIdx.x; e < DNB * DNB; e += 128) {
+        const int c = e >> 6, q = e & 63;
+        o[(size_t)c * DNB + q] = Ts[c][q];                         // (L^-1)[q][c]
+        ot[(size_t)c * DNB + q] = Ts[q][c];                        // transpose image: LiT[c*64 + q] = (L^-1)[c][q]
+    }
 }
-// panel below the diagonal block on the matrix cores: X = A L_kk^-T  =>  W = X (= L D), L = X / D.
+// panel below the diagonal block on the matrix cores: X = A L_kk^-T  =>  W = X (= L D), L = X / D.  L is also written
+// transposed into the upper triangle of K so that the backward solve reads contiguous columns.
 // One workgroup per 64-row tile.
 __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ K, int ld, int kb, int wcol, const double *__restrict__ Dg,
                                                    const double *__restrict__ Linv, double *__restrict__ W) {
@@ -1632,7 +1588,9 @@ __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ K, int l
                 const int row = wr + m * 16 + lk + 4 * v, col = wc + q * 16 + li;
                 const double x = acc[m][q][v];
                 W[(size_t)ti * DNB + row + ((size_t)wcol * DNB + col) * ld] = x;
-                K[(size_t)ti * DNB + row + ((size_t)kb * DNB + col) * ld] = x / Dg[kb * DNB + col];
+                const double lv = x / Dg[kb * DNB + col];
+                K[(size_t)ti * DNB + row + ((size_t)kb * DNB + col) * ld] = lv;
+                K[(size_t)kb * DNB + col + ((size_t)ti * DNB + row) * ld] = lv;         // L' in the (otherwise unused) upper triangle
             }
 }
 // update on the matrix cores: C(ti,tj) -= sum_{q<nkb} W(ti, wcol0+q) * L(tj, kb0+q)'  for tj in [tj_lo, tj_hi), ti >= tj.
@@ -1754,6 +1712,87 @@ __global__ __launch_bounds__(64) void k_ldl_bwd(const double *__restrict__ K, in
     for (int r = 0; r < DNB; r++) sacc -= tile[r][l] * xs[r];
     y[j * DNB + l] = sacc;
 }
+// ---- triangular solves as ONE launch per direction ------------------------------------------------------
+// Workgroup b owns block row b.  Forward: x_b - sum_{k<b} L(b,k) z_k, then z_b = L_bb^-1 (.), published to z; the
+// consumers poll z itself (pre-filled with a signalling-NaN pattern no arithmetic produces) with device-scope
+// loads, so one cross-XCD round trip separates consecutive steps instead of a kernel launch (157 dependent
+// launches of ~11.5 us at n = 1e4).  Backward is the same kernel on the transposed tiles the panel kernel left in
+// the upper triangle, with the block order reversed.  Workgroup b waits only on workgroups dispatched before it,
+// so the grid drains for any dispatch width; a bounded spin turns a lost producer into NaNs + C_CHAIN_ERR.
+static const unsigned long long CH_SENT = 0x7FF4DEADBEEF0001ULL;
+static const int CH_SPIN_MAX = 1 << 22;
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane); hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+__global__ void k_fill_sentinel(int n, double *__restrict__ a, double *__restrict__ b) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        reinterpret_cast<unsigned long long *>(a)[i] = CH_SENT; reinterpret_cast<unsigned long long *>(b)[i] = CH_SENT;
+    }
+}
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_ldl_chain(const double *__restrict__ K, int ld, int nb, const double *__restrict__ Li,
+                                                   const double *__restrict__ Dg, const double *__restrict__ rhs, double *pub,
+                                                   double *__restrict__ yout, Ctrl *ctrl) {
+    __shared__ double part[4][DNB];
+    __shared__ double tot[DNB];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int ndep = blockIdx.x;                                    // blocks this one waits for
+    const int b = FWD ? (int)blockIdx.x : nb - 1 - (int)blockIdx.x;
+    double li[16], cur[16], nxt[16];
+    const double *Lb = Li + (size_t)b * DNB * DNB + (size_t)(w * 16) * DNB + l;
+#pragma unroll
+    for (int q = 0; q < 16; q++) li[q] = Lb[(size_t)q * DNB];
+    const double *Kb = K + (size_t)b * DNB + l + (size_t)(w * 16) * ld;      // tile (b,k): + k*64*ld, element (l, w*16+q): + q*ld
+    auto kof = [&](int j) { return FWD ? j : nb - 1 - j; };
+    if (ndep > 0) {
+        const double *t = Kb + (size_t)kof(0) * DNB * ld;
+#pragma unroll
+        for (int q = 0; q < 16; q++) cur[q] = t[(size_t)q * ld];
+    }
+    double acc = 0.0;
+    bool lost = false;
+    for (int j = 0; j < ndep; j++) {
+        if (j + 1 < ndep) {
+            const double *t = Kb + (size_t)kof(j + 1) * DNB * ld;
+#pragma unroll
+            for (int q = 0; q < 16; q++) nxt[q] = t[(size_t)q * ld];
+        }
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(pub) + (size_t)kof(j) * DNB + w * 16 + (l & 15);
+        unsigned long long bits = CH_SENT;
+        int spins = 0;
+        for (;;) {
+            if (l < 16) bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(l >= 16 || bits != CH_SENT)) break;
+            if (++spins > CH_SPIN_MAX) { lost = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const double v = lost ? __longlong_as_double(0x7FF8000000000000LL) : __longlong_as_double((long long)bits);
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc += cur[q] * lane_bcast(v, q);
+#pragma unroll
+        for (int q = 0; q < 16; q++) cur[q] = nxt[q];
+    }
+    part[w][l] = acc;
+    __syncthreads();
+    if (w == 0) tot[l] = rhs[(size_t)b * DNB + l] - ((part[0][l] + part[1][l]) + (part[2][l] + part[3][l]));
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) s += li[q] * tot[w * 16 + q];
+    part[w][l] = s;                                                 // the first use of part ended before the barrier above
+    __syncthreads();
+    if (w == 0) {
+        double r = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
+        unsigned long long rb = (unsigned long long)__double_as_longlong(r);
+        if (rb == CH_SENT) rb = 0x7FF8000000000000ULL;
+        if (FWD) yout[(size_t)b * DNB + l] = r / Dg[(size_t)b * DNB + l];
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(pub) + (size_t)b * DNB + l, rb, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lost && tid == 0) atomicOr(&ctrl->cnt[C_CHAIN_ERR], 1);
+}
+
 // ---- multi right-hand-side block solves (MFMA) and the low-rank factor update -------------------------
 // The reference keeps its factor current with rank-<=100 LDL' up/downdates when few rows enter or leave
 // (cholmod_interface.c:57-93, newton.c:21-30).  Here the factor K0 = L D L' of the last full factorization
@@ -2313,8 +2352,10 @@ int qdev_configure(QpdoDev *d, int linsolve, double pcg_tol, int pcg_maxit) {
     if (gr && !strcmp(gr, "0")) d->pcg_graph = 0;
     const char *mx = getenv("QPDO_DENSE_MAX_N");
     if (mx && *mx) d->dense_max_n = atoi(mx);
+    const char *ch = getenv("QPDO_DENSE_SOLVE");
+    if (ch && !strcmp(ch, "steps")) d->dense_chain = 0;
     const char *lr = getenv("QPDO_DENSE_LOWRANK");
-    if (lr && !strcmp(lr, "0")) d->wb_enable = 0;
+    if (lr && *lr) d->wb_enable = atoi(lr) != 0;
     if (d->dense_max_n > 18000) d->dense_max_n = 18000;       // the assembly accumulator (n doubles) must fit in LDS
     if (linsolve >= 0) d->linsolve = linsolve;
     else d->linsolve = (d->n <= d->dense_max_n) ? 1 : 0;
@@ -2825,6 +2866,9 @@ static int dense_alloc(QpdoDev *d) {
     }
     if (!rc) rc = dev_alloc(d, &d->dz, (size_t)ld);
     if (!rc) rc = dev_alloc(d, &d->dxw, (size_t)ld);
+    if (!rc) rc = dev_alloc(d, &d->LinvT, (size_t)d->dense_nblk * DNB * DNB);
+    if (!rc) rc = dev_alloc(d, &d->ch_y, (size_t)ld);
+    if (!rc) rc = dev_alloc(d, &d->ch_x, (size_t)ld);
     if (!rc) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         if (e != hipSuccess) rc = set_err(e, "hipFuncSetAttribute", __LINE__);
@@ -2836,7 +2880,6 @@ static int dense_factor(QpdoDev *d) {
     const int n = d->n, ld = d->dense_ld, nb = d->dense_nblk;
     const int g = ld < 1024 ? ld : 1024;
     static const bool kc16 = [] { const char *e = getenv("QPDO_SYRK_KC"); return !(e && atoi(e) == 32); }();
-    static const bool diag1 = [] { const char *e = getenv("QPDO_DENSE_DIAG"); return !(e && atoi(e) == 16); }();
     static const bool lookahead = [] { const char *e = getenv("QPDO_DENSE_LOOKAHEAD"); return !(e && atoi(e) == 0); }();
     hipLaunchKernelGGL(k_dense_assemble, dim3(g), dim3(64), (size_t)n * sizeof(double), d->stream, n, ld, d->Qf.rp, d->Qf.ci, d->Qf.val,
                        d->At.rp, d->At.ci, d->At.val, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)d->d, d->sigma_f, d->Kd);
@@ -2856,8 +2899,7 @@ static int dense_factor(QpdoDev *d) {
         const int Jend = J0 + DOUTER < nb ? J0 + DOUTER : nb;
         double *W = d->Wd + (size_t)(p & 1) * ld * DNB * DOUTER;
         for (int kb = J0; kb < Jend; kb++) {
-            if (diag1) hipLaunchKernelGGL(k_ldl_diag1, dim3(1), dim3(128), 0, d->stream, d->Kd, ld, kb, d->Dg, d->Linv);
-            else       hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(1024), 0, d->stream, d->Kd, ld, kb, d->Dg, d->Linv);
+            hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(128), 0, d->stream, d->Kd, ld, kb, d->Dg, d->Linv, d->LinvT);
             const int below = nb - kb - 1;
             if (below > 0) {
                 hipLaunchKernelGGL(k_ldl_panel, dim3(below), dim3(256), 0, d->stream, d->Kd, ld, kb, kb - J0, (const double *)d->Dg,
@@ -2892,10 +2934,20 @@ static int dense_factor(QpdoDev *d) {
     d->st.factor_count++;
     return 0;
 }
-// z0 = K0^-1 rhs into dxw (ld entries)
+// z0 = K0^-1 rhs; the result (ld entries) is at d->dsol
 static int dense_solve_core(QpdoDev *d) {
     const int n = d->n, ld = d->dense_ld, nb = d->dense_nblk;
     LAUNCH(k_dense_load_rhs, vgrid(ld), n, ld, (const double *)d->rhs, d->dxw);
+    if (d->dense_chain) {          // one launch per direction, block rows chained through polled device-scope loads
+        LAUNCH(k_fill_sentinel, vgrid(ld), ld, d->dz, d->ch_x);
+        LAUNCH(k_ctrl_set_int, 1, d->ctrl, C_CHAIN_ERR, 0);
+        hipLaunchKernelGGL(k_ldl_chain<true>, dim3(nb), dim3(256), 0, d->stream, (const double *)d->Kd, ld, nb, (const double *)d->Linv,
+                           (const double *)d->Dg, (const double *)d->dxw, d->dz, d->ch_y, d->ctrl);
+        hipLaunchKernelGGL(k_ldl_chain<false>, dim3(nb), dim3(256), 0, d->stream, (const double *)d->Kd, ld, nb, (const double *)d->LinvT,
+                           (const double *)d->Dg, (const double *)d->ch_y, d->ch_x, (double *)nullptr, d->ctrl);
+        d->dsol = d->ch_x;
+        return 0;
+    }
     for (int kb = 0; kb < nb; kb++) {
         const int below = nb - kb - 1;
         hipLaunchKernelGGL(k_ldl_fwd, dim3(below > 0 ? below : 1), dim3(64), 0, d->stream, (const double *)d->Kd, ld, kb, (const double *)d->Linv, d->dxw, d->dz);
@@ -2903,17 +2955,18 @@ static int dense_solve_core(QpdoDev *d) {
     LAUNCH(k_dense_scale_d, vgrid(ld), ld, (const double *)d->dz, (const double *)d->Dg, d->dz);
     for (int kb = nb - 1; kb >= 0; kb--)
         hipLaunchKernelGGL(k_ldl_bwd, dim3(kb > 0 ? kb : 1), dim3(64), 0, d->stream, (const double *)d->Kd, ld, kb, (const double *)d->Linv, d->dz, d->dxw);
+    d->dsol = d->dxw;
     return 0;
 }
 static int dense_solve(QpdoDev *d) {
     int rc = dense_solve_core(d); if (rc) return rc;
     const int n = d->n, ld = d->dense_ld, k = d->wb_k;
     if (k == 0) {
-        HIPCHK(hipMemcpyAsync(d->dx, d->dxw, (size_t)n * 8, hipMemcpyDeviceToDevice, d->stream));
+        HIPCHK(hipMemcpyAsync(d->dx, d->dsol, (size_t)n * 8, hipMemcpyDeviceToDevice, d->stream));
         return 0;
     }
     // low-rank correction: dx = z0 - Z (I + W G)^-1 W U z0
-    hipLaunchKernelGGL(k_wb_v, dim3(k), dim3(64), 0, d->stream, (const int *)d->wb_rows, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)d->dxw,
+    hipLaunchKernelGGL(k_wb_v, dim3(k), dim3(64), 0, d->stream, (const int *)d->wb_rows, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)d->dsol,
                        (const double *)d->d, (const double *)d->d_fact, d->wb_v, d->wb_w);
     hipLaunchKernelGGL(k_wb_lu, dim3(1), dim3(1024), (size_t)k * (k + 2) * 8, d->stream, k, (const double *)d->wb_G, (const double *)d->wb_w,
                        (const double *)d->wb_v, d->wb_t);
@@ -2926,10 +2979,10 @@ static int dense_solve(QpdoDev *d) {
         d->st.lowrank_rejects++;
         rc = dense_factor(d); if (rc) return rc;
         rc = dense_solve_core(d); if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(d->dx, d->dxw, (size_t)n * 8, hipMemcpyDeviceToDevice, d->stream));
+        HIPCHK(hipMemcpyAsync(d->dx, d->dsol, (size_t)n * 8, hipMemcpyDeviceToDevice, d->stream));
         return 0;
     }
-    LAUNCH(k_wb_apply, vgrid(n), n, ld, k, (const double *)d->wb_Z, (const double *)d->wb_t, (const double *)d->dxw, d->dx);
+    LAUNCH(k_wb_apply, vgrid(n), n, ld, k, (const double *)d->wb_Z, (const double *)d->wb_t, (const double *)d->dsol, d->dx);
     HIPCHK(hipGetLastError());
     d->st.lowrank_solves++;
     return 0;
@@ -3033,6 +3086,7 @@ int qdev_newton_step(QpdoDev *d, int branch, int n_changed, int proximal, double
     rc = linesearch_device(d, pgrid_A(d), spmv_pgrid(d->Qf)); if (rc) return rc;
     LAUNCH(k_axpy5, vgrid(n > m ? n : m), n, m, d->ctrl, d->x, d->dx, d->Qx, d->Qdx, d->Aty, d->Atdy, d->y, d->dy, d->Ax, d->Adx);
     rc = read_ctrl(d); if (rc) return rc;
+    if (d->linsolve == 1 && d->dense_chain && d->hctrl->cnt[C_CHAIN_ERR]) return set_err(hipErrorUnknown, "dense triangular solve: lost producer", __LINE__);
     *tau_out = d->hctrl->val[V_TAU];
     d->st.newton_passes++;
     return 0;
