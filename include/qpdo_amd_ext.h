@@ -49,6 +49,7 @@ typedef struct {
     long   spmv_Q_samples;
     long   lowrank_solves;  /* dense solves through the low-rank update of the kept factor (cholmod_interface.c:57-93) */
     long   lowrank_cols;    /* rows that entered the low-rank set (one multi-RHS solve column each)                 */
+    long   lowrank_sweeps;  /* refinement sweeps of the low-rank solves (one kept-factor solve + 3 SpMV each)        */
     long   lowrank_rejects; /* low-rank solves abandoned for a refactorization (ill-conditioned downdate)          */
 } QPDOAmdStats;
 

@@ -751,6 +751,7 @@ int qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out) {
     out->spmv_Q_samples = ns;
     out->lowrank_solves = (long)st.lowrank_solves;
     out->lowrank_cols = (long)st.lowrank_cols;
+    out->lowrank_sweeps = (long)st.lowrank_sweeps;
     out->lowrank_rejects = (long)st.lowrank_rejects;
     return 0;
 }

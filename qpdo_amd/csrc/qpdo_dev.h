@@ -44,6 +44,7 @@ typedef struct {
     int32_t linsolve;           /* 0 pcg, 1 dense                            */
     int64_t lowrank_solves;     /* dense solves that used the low-rank update of the kept factor */
     int64_t lowrank_cols;       /* rows that received a low-rank slot (multi-RHS solve columns)   */
+    int64_t lowrank_sweeps;     /* refinement sweeps of those solves (each one kept-factor solve + 3 SpMV) */
     int64_t lowrank_rejects;    /* low-rank solves abandoned for a refactorization (tiny pivot)   */
 } QdevStats;
 
