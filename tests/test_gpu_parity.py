@@ -14,7 +14,7 @@ GOLD = load_golden()
 
 @pytest.fixture(params=["dense", "pcg"])
 def linsolve(request, monkeypatch):
-    """both device linear solvers: dense MFMA LDL' (default for n <= 16384) and Jacobi-PCG"""
+    """both device linear solvers: dense MFMA LDL' (default for n <= 12288) and Jacobi-PCG"""
     monkeypatch.setenv("QPDO_LINSOLVE", request.param)
     return request.param
 
@@ -198,6 +198,38 @@ def test_dense_factor_is_reused_when_weights_do_not_change(gpu_required, monkeyp
     unchanged = sum(1 for t in newton if t["factor_branch"] == 1 and t["n_enter"] + t["n_leave"] == 0)
     assert r["stats"]["factor_count"] <= len(newton) - unchanged
     assert r["stats"]["factor_count"] >= 1 and r["stats"]["lin_iters"] == 0
+
+
+def test_dense_lowrank_update_matches_refactoring(gpu_required, monkeypatch):
+    """few rows entering/leaving: the kept factor is updated instead of rebuilt (reference
+    src/cholmod_interface.c:57-93, src/newton.c:21-30); the solve must be indistinguishable from refactoring"""
+    monkeypatch.setenv("QPDO_LINSOLVE", "dense")
+    p = problems.random_qp(41, 600, 1200, 0.02, 0)
+    monkeypatch.setenv("QPDO_DENSE_LOWRANK", "0")
+    r0 = solver.solve_problem(p, verbose=0)
+    monkeypatch.setenv("QPDO_DENSE_LOWRANK", "1")
+    r1 = solver.solve_problem(p, verbose=0)
+    assert r0["stats"]["lowrank_solves"] == 0
+    assert r1["stats"]["lowrank_solves"] > 0 and r1["stats"]["factor_count"] < r0["stats"]["factor_count"]
+    assert r1["stats"]["lowrank_sweeps"] >= r1["stats"]["lowrank_solves"]
+    assert_same_outcome(r1, r0["info"], r0["x"], r0["y"], p)
+    assert [t["n_active"] for t in r1["trace"]] == [t["n_active"] for t in r0["trace"]]
+    assert [t["factor_branch"] for t in r1["trace"]] == [t["factor_branch"] for t in r0["trace"]]
+
+
+def test_dense_chained_solve_matches_stepwise(gpu_required, monkeypatch):
+    """the one-launch-per-direction triangular solves against the per-block-step kernels (n not a multiple of 64)"""
+    monkeypatch.setenv("QPDO_LINSOLVE", "dense")
+    p = problems.random_qp(43, 1000, 700, 0.03, 50)
+    monkeypatch.setenv("QPDO_DENSE_SOLVE", "steps")
+    r0 = solver.solve_problem(p, verbose=0)
+    monkeypatch.setenv("QPDO_DENSE_SOLVE", "chain")
+    r1 = solver.solve_problem(p, verbose=0)
+    assert_same_outcome(r1, r0["info"], r0["x"], r0["y"], p)
+    o = ob.OracleSolver(p, ob.default_settings())
+    ro = o.solve()
+    assert_same_outcome(r1, ro["info"], ro["x"], ro["y"], p)
+    o.close()
 
 
 def test_config2_full_size_properties(gpu_required):
