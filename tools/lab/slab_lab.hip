@@ -1,0 +1,364 @@
+// Kernel lab (scratch): variants of the LDS-staged slab SpMV on a synthetic C4-shaped CSR matrix generated on the
+// device (m rows x 1000 nnz, n = 1e5 columns, sorted stratified columns, 16-bit slab-local indices).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/lab/slab_lab.hip -o gpurun_out/slab_lab
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+typedef unsigned long long u64;
+__device__ __host__ inline u64 mix(u64 z) { z += 0x9e3779b97f4a7c15ULL; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; return z ^ (z >> 31); }
+
+__global__ void k_gen_slabmajor(int m, int n, int per_row, int W, int nslabs, int rpw, unsigned short *ci16, double *val, int *sp) {
+    const int stride = n / per_row, seg = W / stride;            // entries per (row, slab) segment, exact by construction
+    for (int r = blockIdx.x; r < m; r += gridDim.x) {
+        const int wg = r / rpw, rl = r % rpw;
+        const int Rw = min(rpw, m - wg * rpw);
+        const size_t wbase = (size_t)wg * rpw * per_row;
+        for (int j = threadIdx.x; j < per_row; j += blockDim.x) {
+            const u64 h = mix((u64)r * 1315423911ULL + j);
+            const int c = j * stride + (int)(h % stride);
+            const int sl = j / seg, jj = j % seg;
+            const size_t k = wbase + ((size_t)sl * Rw + rl) * seg + jj;
+            ci16[k] = (unsigned short)(c % W); val[k] = (double)((h >> 20) & 1023) / 512.0 - 1.0;
+        }
+        if (threadIdx.x < nslabs) { const int sl = threadIdx.x; sp[(size_t)r * (nslabs + 1) + sl] = (int)(wbase + ((size_t)sl * Rw + rl) * seg); }
+        if (threadIdx.x == nslabs) sp[(size_t)r * (nslabs + 1) + nslabs] = -1;
+    }
+}
+__global__ void k_gen(int m, int n, int per_row, int W, int nslabs, int *ci, unsigned short *ci16, double *val, int *sp) {
+    const int stride = n / per_row;
+    for (int r = blockIdx.x; r < m; r += gridDim.x) {
+        for (int j = threadIdx.x; j < per_row; j += blockDim.x) {
+            const u64 h = mix((u64)r * 1315423911ULL + j);
+            const int c = j * stride + (int)(h % stride);
+            const size_t k = (size_t)r * per_row + j;
+            ci[k] = c; ci16[k] = (unsigned short)(c % W); val[k] = (double)((h >> 20) & 1023) / 512.0 - 1.0;
+        }
+        __syncthreads();
+        if (threadIdx.x <= nslabs) {
+            const int s = threadIdx.x; int lo = 0, hi = per_row; const size_t b = (size_t)r * per_row;
+            if (s == nslabs) lo = per_row; else { const int target = s * W; while (lo < hi) { int mid = (lo + hi) >> 1; if (ci[b + mid] < target) lo = mid + 1; else hi = mid; } }
+            sp[(size_t)r * (nslabs + 1) + s] = (int)(b + lo);        // fits int: 2e8 nnz
+        }
+        __syncthreads();
+    }
+}
+__global__ void k_fillx(int n, double *x) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] = (double)(mix(i) & 255) / 128.0 - 1.0; }
+
+// V: 0 baseline (4-way unroll + scalar tail), 1 nontemporal loads, 2 predicated 8-way chunks (no tail), 3 = 2 + nontemporal
+template <int V, int TPR, int SEG = 0>
+__global__ __launch_bounds__(1024) void k_slab(int nrows, int ncols, int nslabs, int W, int rows_per_wg, const int *__restrict__ sp,
+                                               const unsigned short *__restrict__ ci16, const double *__restrict__ val,
+                                               const double *__restrict__ x, double *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int next_row;
+    double *xs = lds, *acc = lds + W;
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * rows_per_wg;
+    const int R = min(rows_per_wg, nrows - row0);
+    for (int r = tid; r < R; r += 1024) acc[r] = 0.0;
+    const int lane = tid & (TPR - 1);
+    for (int s = 0; s < nslabs; s++) {
+        const int c0 = s * W, cw = min(W, ncols - c0);
+        __syncthreads();
+        { const int pairs = cw >> 1; const double2 *src = reinterpret_cast<const double2 *>(x + c0); double2 *dst = reinterpret_cast<double2 *>(xs);
+          for (int i = tid; i < pairs; i += 1024) dst[i] = src[i];
+          if ((cw & 1) && tid == 0) xs[cw - 1] = x[c0 + cw - 1];
+          if (tid == 0) next_row = 0; }
+        __syncthreads();
+        const int gw = (tid & 63) / TPR;
+        for (;;) {
+            int base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(&next_row, 64 / TPR);
+            base = __shfl(base, 0, 64);
+            if (base >= R) break;
+            const int r = base + gw;
+            if (r >= R) continue;
+            const int row = row0 + r;
+            const int *spr = sp + (size_t)row * (nslabs + 1) + s;
+            const int beg = spr[0], end = SEG ? beg + SEG : spr[1];
+            double t;
+            if (V == 0 || V == 1) {
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int k = beg + lane;
+                for (; k + 3 * TPR < end; k += 4 * TPR) {
+                    double v0, v1, v2, v3; int a0, a1, a2, a3;
+                    if (V == 1) {
+                        v0 = __builtin_nontemporal_load(val + k); v1 = __builtin_nontemporal_load(val + k + TPR); v2 = __builtin_nontemporal_load(val + k + 2 * TPR); v3 = __builtin_nontemporal_load(val + k + 3 * TPR);
+                        a0 = __builtin_nontemporal_load(ci16 + k); a1 = __builtin_nontemporal_load(ci16 + k + TPR); a2 = __builtin_nontemporal_load(ci16 + k + 2 * TPR); a3 = __builtin_nontemporal_load(ci16 + k + 3 * TPR);
+                    } else {
+                        v0 = val[k]; v1 = val[k + TPR]; v2 = val[k + 2 * TPR]; v3 = val[k + 3 * TPR];
+                        a0 = ci16[k]; a1 = ci16[k + TPR]; a2 = ci16[k + 2 * TPR]; a3 = ci16[k + 3 * TPR];
+                    }
+                    s0 += v0 * xs[a0]; s1 += v1 * xs[a1]; s2 += v2 * xs[a2]; s3 += v3 * xs[a3];
+                }
+                for (; k < end; k += TPR) s0 += val[k] * xs[ci16[k]];
+                t = (s0 + s1) + (s2 + s3);
+            } else if (V == 4 || V == 5) {
+                // 16-byte value loads + 4-byte index loads: the group covers 2*TPR consecutive entries per instruction
+                double sacc[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) sacc[u] = 0.0;
+                const int kb = beg & ~1;                                  // even start: val is 16-byte aligned there
+                for (int k = kb + 2 * lane; k < end; k += 8 * TPR) {
+                    double2 v[4]; ushort2 a[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int kk = k + u * 2 * TPR; const int kc = kk < end ? kk : kb;
+                        v[u] = *reinterpret_cast<const double2 *>(val + kc); a[u] = *reinterpret_cast<const ushort2 *>(ci16 + kc);
+                        if (kk < beg || kk >= end) v[u].x = 0.0;
+                        if (kk + 1 >= end || kk >= end) v[u].y = 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (V == 5) { sacc[2 * u] += v[u].x * (double)a[u].x; sacc[2 * u + 1] += v[u].y * (double)a[u].y; }
+                        else { sacc[2 * u] += v[u].x * xs[a[u].x]; sacc[2 * u + 1] += v[u].y * xs[a[u].y]; }
+                    }
+                }
+                t = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
+            } else if (V == 6) {
+                double sacc[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) sacc[u] = 0.0;
+                for (int k = beg + lane; k < end; k += 8 * TPR) {
+                    double v[8]; int a[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int kk = k + u * TPR; const bool in = kk < end; const int kc = in ? kk : beg; v[u] = val[kc]; a[u] = ci16[kc]; if (!in) v[u] = 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) sacc[u] += v[u] * (double)a[u];
+                }
+                t = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
+            } else {
+                double sacc[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) sacc[u] = 0.0;
+                for (int k = beg + lane; k < end; k += 8 * TPR) {
+                    double v[8]; int a[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int kk = k + u * TPR; const bool in = kk < end; const int kc = in ? kk : beg;
+                        if (V == 3) { v[u] = __builtin_nontemporal_load(val + kc); a[u] = __builtin_nontemporal_load(ci16 + kc); }
+                        else { v[u] = val[kc]; a[u] = ci16[kc]; }
+                        if (!in) v[u] = 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) sacc[u] += v[u] * xs[a[u]];
+                }
+                t = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
+            }
+#pragma unroll
+            for (int o = TPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, TPR);
+            if (lane == 0) acc[r] += t;
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < R; r += 1024) y[row0 + r] = acc[r];
+}
+
+
+__global__ __launch_bounds__(1024) void k_slab_seg(int nrows, int nslabs, int rows_per_wg, const int *__restrict__ sp, int2 *__restrict__ seg) {
+    __shared__ int sums[1024];
+    const int row0 = blockIdx.x * rows_per_wg;
+    const int R = min(rows_per_wg, nrows - row0);
+    if (R <= 0) return;
+    const int T = R * nslabs, chunk = (T + 1023) / 1024;
+    const int t0 = min((int)threadIdx.x * chunk, T), t1 = min(t0 + chunk, T);
+    int c = 0;
+    for (int t = t0; t < t1; t++) { const int sl = t / R, r = t - sl * R; const int *q = sp + (size_t)(row0 + r) * (nslabs + 1) + sl; c += q[1] - q[0]; }
+    sums[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; i++) { const int v = sums[i]; sums[i] = run; run += v; } }
+    __syncthreads();
+    int pos = sp[(size_t)row0 * (nslabs + 1)] + sums[threadIdx.x];
+    for (int t = t0; t < t1; t++) {
+        const int sl = t / R, r = t - sl * R; const int *q = sp + (size_t)(row0 + r) * (nslabs + 1) + sl;
+        const int len = q[1] - q[0];
+        seg[(size_t)(row0 + r) * nslabs + sl] = make_int2(pos, len);
+        pos += len;
+    }
+}
+__global__ __launch_bounds__(256) void k_slab_permute(int nrows, int nslabs, int W, const int *__restrict__ sp, const int2 *__restrict__ seg,
+                                                      const unsigned short *__restrict__ ci16, const double *__restrict__ val, double *__restrict__ vsm,
+                                                      unsigned short *__restrict__ i16sm) {
+    const int lane = threadIdx.x & 15;
+    const int ngroups = gridDim.x * (blockDim.x >> 4);
+    for (int row = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); row < nrows; row += ngroups)
+        for (int sl = 0; sl < nslabs; sl++) {
+            const int src = sp[(size_t)row * (nslabs + 1) + sl];
+            const int2 sg = seg[(size_t)row * nslabs + sl];
+            for (int e = lane; e < sg.y; e += 16) { vsm[sg.x + e] = val[src + e]; i16sm[sg.x + e] = ci16[src + e]; }
+        }
+}
+// production-form kernel: int2 segment table, ternary masking of the products; UNR 16-byte loads in flight per lane
+template <int TPR, int UNR>
+__global__ __launch_bounds__(1024) void k_slab_prod(int nrows, int ncols, int nslabs, int W, int rows_per_wg, const int2 *__restrict__ seg,
+                                                    const unsigned short *__restrict__ i16sm, const double *__restrict__ vsm,
+                                                    const double *__restrict__ x, double *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int next_row;
+    double *xs = lds, *acc = lds + W;
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * rows_per_wg;
+    const int R = min(rows_per_wg, nrows - row0);
+    for (int r = tid; r < R; r += 1024) acc[r] = 0.0;
+    const int lane = tid & (TPR - 1);
+    for (int s = 0; s < nslabs; s++) {
+        const int c0 = s * W, cw = min(W, ncols - c0);
+        __syncthreads();
+        { const int pairs = cw >> 1; const double2 *src = reinterpret_cast<const double2 *>(x + c0); double2 *dst = reinterpret_cast<double2 *>(xs);
+          for (int i = tid; i < pairs; i += 1024) dst[i] = src[i];
+          if ((cw & 1) && tid == 0) xs[cw - 1] = x[c0 + cw - 1];
+          if (tid == 0) next_row = 0; }
+        __syncthreads();
+        const int gw = (tid & 63) / TPR;
+        for (;;) {
+            int base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(&next_row, 64 / TPR);
+            base = __shfl(base, 0, 64);
+            if (base >= R) break;
+            const int r = base + gw;
+            if (r >= R) continue;
+            const int row = row0 + r;
+            const int2 sg = seg[(size_t)row * nslabs + s];
+            const int beg = sg.x, end = sg.x + sg.y;
+            const int kb = beg & ~1;
+            double sa[2 * UNR];
+#pragma unroll
+            for (int u = 0; u < 2 * UNR; u++) sa[u] = 0.0;
+            for (int k = kb + 2 * lane; k < end; k += 2 * UNR * TPR) {
+                double2 v[UNR]; int ax[UNR], ay[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; u++) {
+                    const int kk = k + u * 2 * TPR; const int kc = kk < end ? kk : kb;
+                    v[u] = *reinterpret_cast<const double2 *>(vsm + kc);
+                    const ushort2 a = *reinterpret_cast<const ushort2 *>(i16sm + kc); ax[u] = a.x; ay[u] = a.y;
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; u++) {
+                    const int kk = k + u * 2 * TPR;
+                    const double px = v[u].x * xs[ax[u]], py = v[u].y * xs[ay[u]];
+                    sa[2 * u] += (kk >= beg && kk < end) ? px : 0.0;
+                    sa[2 * u + 1] += (kk + 1 < end) ? py : 0.0;
+                }
+            }
+            double t = 0.0;
+#pragma unroll
+            for (int u = 0; u < 2 * UNR; u++) t += sa[u];
+#pragma unroll
+            for (int o = TPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, TPR);
+            if (lane == 0) acc[r] += t;
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < R; r += 1024) y[row0 + r] = acc[r];
+}
+template <int TPR, int UNR>
+static void run_prod(const char *name, int m, int n, int nslabs, int W, int rpw, const int2 *seg, const unsigned short *i16, const double *v, const double *x, double *y, double nnz, const std::vector<double> &ref) {
+    const int grid = (m + rpw - 1) / rpw; const size_t lds = (size_t)(W + rpw) * 8;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slab_prod<TPR, UNR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL((k_slab_prod<TPR, UNR>), dim3(grid), dim3(1024), lds, 0, m, n, nslabs, W, rpw, seg, i16, v, x, y);
+    CK(hipEventRecord(e0, 0));
+    for (int w = 0; w < 10; w++) hipLaunchKernelGGL((k_slab_prod<TPR, UNR>), dim3(grid), dim3(1024), lds, 0, m, n, nslabs, W, rpw, seg, i16, v, x, y);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+    std::vector<double> h(m); CK(hipMemcpy(h.data(), y, (size_t)m * 8, hipMemcpyDeviceToHost));
+    double err = 0.0; for (int i = 0; i < m; i++) { double dd = fabs(h[i] - ref[i]); if (dd > err) err = dd; }
+    printf("%-34s %.3f ms  algorithmic %.2f TB/s  maxdiff %.2e\n", name, ms, nnz * 12 / ms / 1e9, err); fflush(stdout);
+}
+__global__ void k_seg_rowmajor(int m, int nslabs, const int *__restrict__ sp, int2 *__restrict__ seg) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m * nslabs; i += gridDim.x * blockDim.x) { const int r = i / nslabs, sl = i % nslabs; const int *q = sp + (size_t)r * (nslabs + 1) + sl; seg[i] = make_int2(q[0], q[1] - q[0]); }
+}
+__global__ void k_seg_from_sp(int m, int nslabs, int len, const int *__restrict__ sp, int2 *__restrict__ seg) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m * nslabs; i += gridDim.x * blockDim.x) { const int r = i / nslabs, sl = i % nslabs; seg[i] = make_int2(sp[(size_t)r * (nslabs + 1) + sl], len); }
+}
+template <int V, int TPR, int SEG = 0>
+static double run(const char *name, int m, int n, int nslabs, int W, int rpw, const int *sp, const unsigned short *ci16, const double *val, const double *x, double *y, double nnz, std::vector<double> &ref) {
+    const size_t lds = (size_t)(W + rpw) * 8;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slab<V, TPR, SEG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = (m + rpw - 1) / rpw;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL((k_slab<V, TPR, SEG>), dim3(grid), dim3(1024), lds, 0, m, n, nslabs, W, rpw, sp, ci16, val, x, y);
+    CK(hipEventRecord(e0, 0));
+    const int reps = 10;
+    for (int w = 0; w < reps; w++) hipLaunchKernelGGL((k_slab<V, TPR, SEG>), dim3(grid), dim3(1024), lds, 0, m, n, nslabs, W, rpw, sp, ci16, val, x, y);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    std::vector<double> h(m); CK(hipMemcpy(h.data(), y, (size_t)m * 8, hipMemcpyDeviceToHost));
+    double err = 0.0; if (ref.empty()) ref = h; else for (int i = 0; i < m; i++) { double d = fabs(h[i] - ref[i]); if (d > err) err = d; }
+    printf("%-28s %.3f ms  actual %.2f TB/s (10 B/nnz)  algorithmic %.2f TB/s (12 B/nnz)  maxdiff %.2e\n", name, ms, nnz * 10 / ms / 1e9, nnz * 12 / ms / 1e9, err);
+    fflush(stdout);
+    return ms;
+}
+int main() {
+    const int m = 200000, n = 100000, per_row = 1000;
+    const int rpw = (m + 255) / 256;                  // one workgroup per CU
+    int W = ((160 * 1024 - 1024) / 8 - rpw) & ~1;     // x slice + accumulators fill the LDS
+    const int nslabs = (n + W - 1) / W;
+    W = (((n + nslabs - 1) / nslabs) + 1) & ~1;
+    printf("m %d n %d nnz/row %d rows/wg %d W %d nslabs %d\n", m, n, per_row, rpw, W, nslabs);
+    const double nnz = (double)m * per_row;
+    int *ci, *sp; unsigned short *ci16; double *val, *x, *y;
+    CK(hipMalloc(&ci, (size_t)nnz * 4)); CK(hipMalloc(&ci16, (size_t)nnz * 2)); CK(hipMalloc(&val, (size_t)nnz * 8));
+    CK(hipMalloc(&sp, (size_t)m * (nslabs + 1) * 4)); CK(hipMalloc(&x, (size_t)n * 8)); CK(hipMalloc(&y, (size_t)m * 8));
+    hipLaunchKernelGGL(k_gen, dim3(4096), dim3(256), 0, 0, m, n, per_row, W, nslabs, ci, ci16, val, sp);
+    hipLaunchKernelGGL(k_fillx, dim3(256), dim3(256), 0, 0, n, x);
+    CK(hipDeviceSynchronize());
+    std::vector<double> ref;
+    run<0, 8>("V0 baseline tpr8", m, n, nslabs, W, rpw, sp, ci16, val, x, y, nnz, ref);
+    run<2, 8>("V2 pred 8-way tpr8", m, n, nslabs, W, rpw, sp, ci16, val, x, y, nnz, ref);
+    run<2, 16>("V2 pred 8-way tpr16", m, n, nslabs, W, rpw, sp, ci16, val, x, y, nnz, ref);
+    run<2, 32>("V2 pred 8-way tpr32", m, n, nslabs, W, rpw, sp, ci16, val, x, y, nnz, ref);
+    run<4, 8>("V4 double2 tpr8", m, n, nslabs, W, rpw, sp, ci16, val, x, y, nnz, ref);
+    run<4, 16>("V4 double2 tpr16", m, n, nslabs, W, rpw, sp, ci16, val, x, y, nnz, ref);
+    run<4, 32>("V4 double2 tpr32", m, n, nslabs, W, rpw, sp, ci16, val, x, y, nnz, ref);
+    run<5, 8>("V5 double2 no-gather tpr8", m, n, nslabs, W, rpw, sp, ci16, val, x, y, nnz, ref);
+    run<6, 16>("V6 no-gather tpr16", m, n, nslabs, W, rpw, sp, ci16, val, x, y, nnz, ref);
+    run<0, 8>("V0 baseline tpr8 (again)", m, n, nslabs, W, rpw, sp, ci16, val, x, y, nnz, ref);
+    {   // production pipeline on the general (uneven) row-major data: seg table + permute, then the int2/ternary kernel
+        double *vsm; unsigned short *i16sm; int2 *seg;
+        CK(hipMalloc(&vsm, ((size_t)nnz + 2) * 8)); CK(hipMalloc(&i16sm, ((size_t)nnz + 2) * 2)); CK(hipMalloc(&seg, (size_t)m * nslabs * 8));
+        CK(hipMemset(vsm, 0, ((size_t)nnz + 2) * 8)); CK(hipMemset(i16sm, 0, ((size_t)nnz + 2) * 2));
+        const int grid = (m + rpw - 1) / rpw;
+        hipLaunchKernelGGL(k_slab_seg, dim3(grid), dim3(1024), 0, 0, m, nslabs, rpw, (const int *)sp, seg);
+        hipLaunchKernelGGL(k_slab_permute, dim3(2048), dim3(256), 0, 0, m, nslabs, W, (const int *)sp, (const int2 *)seg, (const unsigned short *)ci16, (const double *)val, vsm, i16sm);
+        CK(hipDeviceSynchronize());
+        int2 *segrm; CK(hipMalloc(&segrm, (size_t)m * nslabs * 8));
+        hipLaunchKernelGGL(k_seg_rowmajor, dim3(1024), dim3(256), 0, 0, m, nslabs, (const int *)sp, segrm);
+        CK(hipDeviceSynchronize());
+        run_prod<16, 4>("PROD slab-major tpr16 unr4", m, n, nslabs, W, rpw, seg, i16sm, vsm, x, y, nnz, ref);
+        run_prod<16, 6>("PROD slab-major tpr16 unr6", m, n, nslabs, W, rpw, seg, i16sm, vsm, x, y, nnz, ref);
+        run_prod<16, 8>("PROD slab-major tpr16 unr8", m, n, nslabs, W, rpw, seg, i16sm, vsm, x, y, nnz, ref);
+        run_prod<8, 8>("PROD slab-major tpr8 unr8", m, n, nslabs, W, rpw, seg, i16sm, vsm, x, y, nnz, ref);
+        run_prod<8, 12>("PROD slab-major tpr8 unr12", m, n, nslabs, W, rpw, seg, i16sm, vsm, x, y, nnz, ref);
+        run_prod<32, 4>("PROD slab-major tpr32 unr4", m, n, nslabs, W, rpw, seg, i16sm, vsm, x, y, nnz, ref);
+        run_prod<16, 4>("PROD row-major tpr16 unr4", m, n, nslabs, W, rpw, segrm, ci16, val, x, y, nnz, ref);
+        run_prod<16, 8>("PROD row-major tpr16 unr8", m, n, nslabs, W, rpw, segrm, ci16, val, x, y, nnz, ref);
+        run_prod<8, 12>("PROD row-major tpr8 unr12", m, n, nslabs, W, rpw, segrm, ci16, val, x, y, nnz, ref);
+        CK(hipFree(segrm));
+        CK(hipFree(vsm)); CK(hipFree(i16sm)); CK(hipFree(seg));
+    }
+    // ---- slab-major storage: per workgroup, all row segments of slab 0, then of slab 1, ... (sequential stream per slab phase)
+    {
+        const int stride = 100, W2 = 16600, n2 = 99600, pr2 = 996, ns2 = 6;
+        const double nnz2 = (double)m * pr2;
+        hipLaunchKernelGGL(k_gen_slabmajor, dim3(4096), dim3(256), 0, 0, m, n2, pr2, W2, ns2, rpw, ci16, val, sp);
+        CK(hipDeviceSynchronize());
+        std::vector<double> ref2;
+        printf("slab-major layout: n %d W %d nslabs %d seg %d\n", n2, W2, ns2, W2 / stride);
+        run<2, 8, 166>("SM V2 pred 8-way tpr8", m, n2, ns2, W2, rpw, sp, ci16, val, x, y, nnz2, ref2);
+        run<2, 16, 166>("SM V2 pred 8-way tpr16", m, n2, ns2, W2, rpw, sp, ci16, val, x, y, nnz2, ref2);
+        run<4, 8, 166>("SM V4 double2 tpr8", m, n2, ns2, W2, rpw, sp, ci16, val, x, y, nnz2, ref2);
+        run<4, 16, 166>("SM V4 double2 tpr16", m, n2, ns2, W2, rpw, sp, ci16, val, x, y, nnz2, ref2);
+        run<4, 32, 166>("SM V4 double2 tpr32", m, n2, ns2, W2, rpw, sp, ci16, val, x, y, nnz2, ref2);
+        {   // the production-form kernel on the directly generated slab-major data
+            int2 *seg; CK(hipMalloc(&seg, (size_t)m * ns2 * 8));
+            hipLaunchKernelGGL(k_seg_from_sp, dim3(1024), dim3(256), 0, 0, m, ns2, 166, (const int *)sp, seg);
+            CK(hipDeviceSynchronize());
+            run_prod<16, 4>("SM data, PROD tpr16 unr4", m, n2, ns2, W2, rpw, seg, ci16, val, x, y, nnz2, ref2);
+            run_prod<16, 8>("SM data, PROD tpr16 unr8", m, n2, ns2, W2, rpw, seg, ci16, val, x, y, nnz2, ref2);
+        }
+    }
+    return 0;
+}
