@@ -7,9 +7,12 @@
  *
  * Environment variables read once per qpdo_setup:
  *   QPDO_DEVICE      HIP device ordinal (default: LOCAL_RANK if set, else 0)
- *   QPDO_LINSOLVE    "pcg" | "dense" | "auto" (default auto: dense LDL' for n <= QPDO_DENSE_MAX_N = 8192)
+ *   QPDO_LINSOLVE    "pcg" | "dense" | "auto" (default auto: dense LDL' for n <= QPDO_DENSE_MAX_N = 12288)
  *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change instead of the low-rank update of the kept dense factor
  *   QPDO_DENSE_LOOKAHEAD "0": factor on one stream (no overlap of the next panel with the trailing update)
+ *   QPDO_DENSE_RESERVE_CUS  CUs left out of the trailing-update stream's mask (default 32; 0 = no mask)
+ *   QPDO_DENSE_SOLVE "steps": per-block-step triangular solve kernels instead of the one-launch chained solves
+ *   QPDO_SLAB_TPR    lanes per row segment of the slab SpMV (8 | 16 | 32, default 16)
  *   QPDO_SPMV        "slab" | "plain" (default: LDS-staged slab kernel for matrices >= 192 MB)
  *   QPDO_DEFLATE     "0" disables the heavy-row deflation of the PCG preconditioner
  *   QPDO_IDX16       "0" disables the 16-bit slab-local column indices

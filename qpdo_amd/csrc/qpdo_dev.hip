@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(256) void k_defl_w(const int *__restrict__ done, in
     const int a = threadIdx.x;
     if (a >= r) return;
     double sacc = 0.0;
-    for (int b = 0; b < r; b++) sacc += Sinv[a * DEFL_MAX + b] * v[b];
+    for (int b = 0; b < r; b++) sacc += Sinv[b * DEFL_MAX + a] * v[b];      // S^-1 is symmetric: read it along the lanes
     th[list[a]] = sacc;
 }
 struct EpiDeflZ {                          // z = u - (A_h' w) ./ P ; partial r.z
