@@ -12,6 +12,7 @@
  *   QPDO_DENSE_LOOKAHEAD "0": factor on one stream (no overlap of the next panel with the trailing update)
  *   QPDO_DENSE_RESERVE_CUS  CUs left out of the trailing-update stream's mask (default 32; 0 = no mask)
  *   QPDO_DENSE_SOLVE "steps": per-block-step triangular solve kernels instead of the one-launch chained solves
+ *   QPDO_SETUP_THREADS  host threads of the CSC -> CSR conversions in qpdo_setup (default min(16, cores)); QPDO_SETUP_PROF=1 prints phase times
  *   QPDO_SLAB_TPR    lanes per row segment of the slab SpMV (8 | 16 | 32, default 16)
  *   QPDO_SPMV        "slab" | "plain" (default: LDS-staged slab kernel for matrices >= 192 MB)
  *   QPDO_DEFLATE     "0" disables the heavy-row deflation of the PCG preconditioner

@@ -69,10 +69,13 @@ def build_lib(force=False, verbose=False):
         objs.append(o)
     for s in C_SOURCES:
         o = os.path.join(CSRC, s + ".o")
-        subprocess.check_call(["gcc", "-std=gnu11", "-ffp-contract=off", "-Wall", *common,
+        subprocess.check_call(["gcc", "-std=gnu11", "-ffp-contract=off", "-fopenmp", "-Wall", *common,
                                "-c", os.path.join(CSRC, s), "-o", o])
         objs.append(o)
-    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-lm", "-lpthread", "-L/opt/rocm/lib", "-lrccl"])
+    # the host driver is gcc/OpenMP code (parallel CSC -> CSR conversions in qpdo_setup): GNU OpenMP runtime
+    gomp = subprocess.check_output(["gcc", "-print-file-name=libgomp.so"], text=True).strip()
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-lm", "-lpthread",
+                           "-L/opt/rocm/lib", "-lrccl", gomp])
     return LIB_PATH
 
 

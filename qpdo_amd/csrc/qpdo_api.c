@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <omp.h>
 #include <pthread.h>
 
 #include "qpdo.h"
@@ -126,6 +127,8 @@ static QPDOSettings *copy_settings(const QPDOSettings *s) {   /* src/util.c:21-4
     return n;
 }
 
+static int env_int_early(const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
+static double wall_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 /* ---- matrix intake: CSC (int32 or int64 indices) -> int32 CSR triples ------------- */
 typedef struct { int32_t nrows, ncols; int64_t nnz; int32_t *rp, *ci; double *val; } HostCsr;
 static void host_csr_free(HostCsr *h) { free(h->rp); free(h->ci); free(h->val); memset(h, 0, sizeof(*h)); }
@@ -141,6 +144,26 @@ static int sparse_ok(const cholmod_sparse *M) {
     if (idx_at(M->p, M->itype, (int64_t)M->ncol) >= (int64_t)INT32_MAX) return 0;
     return 1;
 }
+/* release the staging copies on a detached thread (falls back to freeing in place) */
+typedef struct { HostCsr h[3]; } FreeJob;
+static void *free_job(void *arg) { FreeJob *j = (FreeJob *)arg; for (int i = 0; i < 3; i++) host_csr_free(&j->h[i]); free(j); return NULL; }
+static void host_csr_free_async(HostCsr *a, HostCsr *b, HostCsr *c) {
+    FreeJob *j = malloc(sizeof(FreeJob));
+    pthread_t th; pthread_attr_t at;
+    if (j) {
+        j->h[0] = *a; j->h[1] = *b; j->h[2] = *c;
+        pthread_attr_init(&at); pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+        if (pthread_create(&th, &at, free_job, j) == 0) { pthread_attr_destroy(&at); memset(a, 0, sizeof(*a)); memset(b, 0, sizeof(*b)); memset(c, 0, sizeof(*c)); return; }
+        pthread_attr_destroy(&at); free(j);
+    }
+    host_csr_free(a); host_csr_free(b); host_csr_free(c);
+}
+/* host threads for the conversions (OpenMP; QPDO_SETUP_THREADS, default min(16, cores)) */
+static int conv_threads(void) {
+    int t = env_int_early("QPDO_SETUP_THREADS", 0);
+    if (t <= 0) { t = omp_get_max_threads(); if (t > 16) t = 16; }
+    return t < 1 ? 1 : t;
+}
 /* the CSC arrays of an r x c matrix are the CSR arrays of its c x r transpose */
 static int csc_as_csr_of_transpose(const cholmod_sparse *M, HostCsr *out) {
     const int64_t nc = (int64_t)M->ncol, nnz = idx_at(M->p, M->itype, nc);
@@ -150,104 +173,117 @@ static int csc_as_csr_of_transpose(const cholmod_sparse *M, HostCsr *out) {
     out->ci = malloc((size_t)(nnz ? nnz : 1) * sizeof(int32_t));
     out->val = malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
     if (!out->rp || !out->ci || !out->val) { host_csr_free(out); return 0; }
-    for (int64_t j = 0; j <= nc; j++) out->rp[j] = (int32_t)idx_at(M->p, M->itype, j);
-    for (int64_t k = 0; k < nnz; k++) out->ci[k] = (int32_t)idx_at(M->i, M->itype, k);
-    memcpy(out->val, M->x, (size_t)nnz * sizeof(double));
+    const int T = conv_threads();
+    const double *x = M->x;
+#pragma omp parallel num_threads(T) if (nnz > 200000)
+    {
+#pragma omp for schedule(static) nowait
+        for (int64_t j = 0; j <= nc; j++) out->rp[j] = (int32_t)idx_at(M->p, M->itype, j);
+#pragma omp for schedule(static)
+        for (int64_t k = 0; k < nnz; k++) { out->ci[k] = (int32_t)idx_at(M->i, M->itype, k); out->val[k] = x[k]; }
+    }
     return 1;
 }
-/* CSR of the r x c matrix itself: one counting pass, rows come out column-sorted */
+/* CSR of the r x c matrix itself, rows column-sorted.  The columns are cut into T contiguous ranges of equal
+ * nnz; thread t counts its range per row, a prefix over (row, t) gives every thread its first slot in each row,
+ * and the threads scatter their ranges in column order -- the result is the one a serial counting pass gives. */
 static int csc_to_csr(const cholmod_sparse *M, HostCsr *out) {
     const int64_t nr = (int64_t)M->nrow, nc = (int64_t)M->ncol, nnz = idx_at(M->p, M->itype, nc);
     memset(out, 0, sizeof(*out));
     out->nrows = (int32_t)nr; out->ncols = (int32_t)nc; out->nnz = nnz;
+    int T = conv_threads();
+    if ((nnz < 200000 && env_int_early("QPDO_SETUP_THREADS", 0) <= 0) || (int64_t)T * nr > 400000000LL) T = 1;
     out->rp = calloc((size_t)nr + 1, sizeof(int32_t));
     out->ci = malloc((size_t)(nnz ? nnz : 1) * sizeof(int32_t));
     out->val = malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
-    int32_t *next = malloc((size_t)(nr ? nr : 1) * sizeof(int32_t));
-    if (!out->rp || !out->ci || !out->val || !next) { free(next); host_csr_free(out); return 0; }
-    for (int64_t k = 0; k < nnz; k++) out->rp[idx_at(M->i, M->itype, k) + 1]++;
-    for (int64_t i = 0; i < nr; i++) out->rp[i + 1] += out->rp[i];
-    for (int64_t i = 0; i < nr; i++) next[i] = out->rp[i];
+    int32_t *cnt = calloc((size_t)T * (size_t)(nr ? nr : 1), sizeof(int32_t));     /* cnt[t*nr + i] */
+    int64_t *cut = malloc(((size_t)T + 1) * sizeof(int64_t));                          /* column ranges */
+    if (!out->rp || !out->ci || !out->val || !cnt || !cut) { free(cnt); free(cut); host_csr_free(out); return 0; }
+    cut[0] = 0; cut[T] = nc;
+    for (int t = 1; t < T; t++) {            /* first column whose start offset reaches t/T of the entries */
+        const int64_t target = nnz / T * t;
+        int64_t lo = cut[t - 1], hi = nc;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (idx_at(M->p, M->itype, mid) < target) lo = mid + 1; else hi = mid; }
+        cut[t] = lo;
+    }
     const double *x = M->x;
-    for (int64_t j = 0; j < nc; j++) {
-        const int64_t b = idx_at(M->p, M->itype, j), e = idx_at(M->p, M->itype, j + 1);
-        for (int64_t k = b; k < e; k++) {
-            const int32_t s = next[idx_at(M->i, M->itype, k)]++;
-            out->ci[s] = (int32_t)j; out->val[s] = x[k];
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        int32_t *c = cnt + (size_t)t * (size_t)nr;
+        const int64_t kb = idx_at(M->p, M->itype, cut[t]), ke = idx_at(M->p, M->itype, cut[t + 1]);
+        for (int64_t k = kb; k < ke; k++) c[idx_at(M->i, M->itype, k)]++;
+#pragma omp barrier
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < nr; i++) {   /* row totals; cnt becomes the offset of thread t inside row i */
+            int32_t run = 0;
+            for (int tt = 0; tt < T; tt++) { const int32_t v = cnt[(size_t)tt * (size_t)nr + i]; cnt[(size_t)tt * (size_t)nr + i] = run; run += v; }
+            out->rp[i + 1] = run;
+        }
+#pragma omp single
+        for (int64_t i = 0; i < nr; i++) out->rp[i + 1] += out->rp[i];
+        for (int64_t j = cut[t]; j < cut[t + 1]; j++) {
+            const int64_t b = idx_at(M->p, M->itype, j), e = idx_at(M->p, M->itype, j + 1);
+            for (int64_t k = b; k < e; k++) {
+                const int64_t i = idx_at(M->i, M->itype, k);
+                const int32_t s = out->rp[i] + c[i]++;
+                out->ci[s] = (int32_t)j; out->val[s] = x[k];
+            }
         }
     }
-    free(next);
+    free(cnt); free(cut);
     return 1;
 }
-/* full symmetric CSR of Q from one stored triangle (stype -1 lower, +1 upper) or from full
- * storage (stype 0).  Column-ordered fill keeps every row sorted by column. */
+/* full symmetric CSR of Q from one stored triangle (stype -1 lower, +1 upper) or from full storage (stype 0).
+ * Lower stored: row i = CSR(L) row i (columns <= i, ascending) followed by column i of L below the diagonal
+ * (ascending rows = ascending columns of the mirror).  Upper stored: column i of U up to the diagonal, then
+ * CSR(U) row i beyond it.  Rows come out column-sorted for column-sorted input; entries on the wrong side of
+ * the stored triangle are ignored, as CHOLMOD does for stype != 0. */
 static int sym_to_full_csr(const cholmod_sparse *Q, HostCsr *out) {
-    const int64_t n = (int64_t)Q->ncol, nnz_in = idx_at(Q->p, Q->itype, n);
+    const int64_t n = (int64_t)Q->ncol;
     const int st = Q->stype;
     if (st == 0) return csc_as_csr_of_transpose(Q, out);      /* symmetric: transpose == itself */
+    HostCsr R;                                                /* CSR of the stored matrix (all its entries) */
+    if (!csc_to_csr(Q, &R)) return 0;
     memset(out, 0, sizeof(*out));
     out->nrows = out->ncols = (int32_t)n;
     out->rp = calloc((size_t)n + 1, sizeof(int32_t));
-    int32_t *next = malloc((size_t)(n ? n : 1) * sizeof(int32_t));
-    if (!out->rp || !next) { free(next); host_csr_free(out); return 0; }
-    int64_t total = 0;
-    for (int64_t j = 0; j < n; j++) {
-        const int64_t b = idx_at(Q->p, Q->itype, j), e = idx_at(Q->p, Q->itype, j + 1);
-        for (int64_t k = b; k < e; k++) {
-            const int64_t i = idx_at(Q->i, Q->itype, k);
-            if (i == j) { out->rp[i + 1]++; total++; }
-            else if ((st < 0 && i > j) || (st > 0 && i < j)) { out->rp[i + 1]++; out->rp[j + 1]++; total += 2; }
-        }
+    if (!out->rp) { host_csr_free(&R); return 0; }
+    const int T = conv_threads();
+    const int par = R.nnz > 200000;
+    /* an entry (i,j) of the stored matrix counts when it is on the stored side or the diagonal */
+#define KEEP_CSR(i, j) ((st < 0) ? ((j) <= (i)) : ((j) >= (i)))      /* CSR row i keeps (i,j): own triangle incl. diagonal */
+#define KEEP_MIR(i, j) ((st < 0) ? ((i) > (j)) : ((i) < (j)))        /* CSC column j entry (i,j) mirrors into row j as (j,i) */
+#pragma omp parallel for schedule(static) num_threads(T) if (par)
+    for (int64_t i = 0; i < n; i++) {
+        int32_t c = 0;
+        for (int32_t k = R.rp[i]; k < R.rp[i + 1]; k++) c += KEEP_CSR(i, (int64_t)R.ci[k]);
+        const int64_t b = idx_at(Q->p, Q->itype, i), e = idx_at(Q->p, Q->itype, i + 1);
+        for (int64_t k = b; k < e; k++) c += KEEP_MIR(idx_at(Q->i, Q->itype, k), i);
+        out->rp[i + 1] = c;
     }
-    if (total >= (int64_t)INT32_MAX) { free(next); host_csr_free(out); return 0; }
-    (void)nnz_in;
-    for (int64_t i = 0; i < n; i++) out->rp[i + 1] += out->rp[i];
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; i++) { total += out->rp[i + 1]; if (total >= (int64_t)INT32_MAX) { host_csr_free(&R); host_csr_free(out); return 0; } out->rp[i + 1] = (int32_t)total; }
     out->nnz = total;
     out->ci = malloc((size_t)(total ? total : 1) * sizeof(int32_t));
     out->val = malloc((size_t)(total ? total : 1) * sizeof(double));
-    if (!out->ci || !out->val) { free(next); host_csr_free(out); return 0; }
-    for (int64_t i = 0; i < n; i++) next[i] = out->rp[i];
+    if (!out->ci || !out->val) { host_csr_free(&R); host_csr_free(out); return 0; }
     const double *x = Q->x;
-    if (st < 0) {
-        /* lower stored: column j supplies (i<-j) for i>j into row i (ascending j), then row j takes its
-         * diagonal and the mirrored (j<-i), i ascending, after all its lower entries (columns < j). */
-        for (int64_t j = 0; j < n; j++) {
-            const int64_t b = idx_at(Q->p, Q->itype, j), e = idx_at(Q->p, Q->itype, j + 1);
-            for (int64_t k = b; k < e; k++) {       /* diagonal first so row j stays sorted */
-                const int64_t i = idx_at(Q->i, Q->itype, k);
-                if (i == j) { const int32_t s = next[j]++; out->ci[s] = (int32_t)j; out->val[s] = x[k]; }
-            }
-            for (int64_t k = b; k < e; k++) {
-                const int64_t i = idx_at(Q->i, Q->itype, k);
-                if (i > j) {
-                    int32_t s = next[i]++; out->ci[s] = (int32_t)j; out->val[s] = x[k];
-                    s = next[j]++; out->ci[s] = (int32_t)i; out->val[s] = x[k];
-                }
-            }
-        }
-    } else {
-        /* upper stored: entry (i,j), i<j.  Pass 1 (ascending j) fills the lower mirror (j<-i) ... rows
-         * would not come out sorted in one pass, so do two passes: lower mirrors + diagonal, then uppers. */
-        for (int64_t j = 0; j < n; j++) {
-            const int64_t b = idx_at(Q->p, Q->itype, j), e = idx_at(Q->p, Q->itype, j + 1);
-            for (int64_t k = b; k < e; k++) {
-                const int64_t i = idx_at(Q->i, Q->itype, k);
-                if (i < j) { const int32_t s = next[j]++; out->ci[s] = (int32_t)i; out->val[s] = x[k]; }
-            }
-            for (int64_t k = b; k < e; k++) {
-                const int64_t i = idx_at(Q->i, Q->itype, k);
-                if (i == j) { const int32_t s = next[j]++; out->ci[s] = (int32_t)j; out->val[s] = x[k]; }
-            }
-        }
-        for (int64_t j = 0; j < n; j++) {
-            const int64_t b = idx_at(Q->p, Q->itype, j), e = idx_at(Q->p, Q->itype, j + 1);
-            for (int64_t k = b; k < e; k++) {
-                const int64_t i = idx_at(Q->i, Q->itype, k);
-                if (i < j) { const int32_t s = next[i]++; out->ci[s] = (int32_t)j; out->val[s] = x[k]; }
-            }
+#pragma omp parallel for schedule(static) num_threads(T) if (par)
+    for (int64_t i = 0; i < n; i++) {
+        int32_t s = out->rp[i];
+        const int64_t b = idx_at(Q->p, Q->itype, i), e = idx_at(Q->p, Q->itype, i + 1);
+        if (st < 0) {       /* columns <= i from the CSR row, then the mirrored column below the diagonal */
+            for (int32_t k = R.rp[i]; k < R.rp[i + 1]; k++) if (KEEP_CSR(i, (int64_t)R.ci[k])) { out->ci[s] = R.ci[k]; out->val[s] = R.val[k]; s++; }
+            for (int64_t k = b; k < e; k++) { const int64_t r = idx_at(Q->i, Q->itype, k); if (KEEP_MIR(r, i)) { out->ci[s] = (int32_t)r; out->val[s] = x[k]; s++; } }
+        } else {            /* mirrored column above the diagonal, then columns >= i from the CSR row */
+            for (int64_t k = b; k < e; k++) { const int64_t r = idx_at(Q->i, Q->itype, k); if (KEEP_MIR(r, i)) { out->ci[s] = (int32_t)r; out->val[s] = x[k]; s++; } }
+            for (int32_t k = R.rp[i]; k < R.rp[i + 1]; k++) if (KEEP_CSR(i, (int64_t)R.ci[k])) { out->ci[s] = R.ci[k]; out->val[s] = R.val[k]; s++; }
         }
     }
-    free(next);
+#undef KEEP_CSR
+#undef KEEP_MIR
+    host_csr_free(&R);
     return 1;
 }
 
@@ -343,9 +379,14 @@ QPDOWorkspace *qpdo_setup(const QPDOData *data, const QPDOSettings *settings) {
 
     {   /* matrices to the device */
         HostCsr Ar = {0}, At = {0}, Qf = {0};
+        const int prof = env_int("QPDO_SETUP_PROF", 0);
+        double t0 = wall_now();
         int ok = csc_to_csr(data->A, &Ar);
+        if (prof) { fprintf(stderr, "[setup] CSR(A)            %.3f s\n", wall_now() - t0); t0 = wall_now(); }
         ok = ok && csc_as_csr_of_transpose(data->A, &At);
+        if (prof) { fprintf(stderr, "[setup] CSR(A') narrowing %.3f s\n", wall_now() - t0); t0 = wall_now(); }
         ok = ok && sym_to_full_csr(data->Q, &Qf);
+        if (prof) { fprintf(stderr, "[setup] full CSR(Q)       %.3f s\n", wall_now() - t0); t0 = wall_now(); }
         if (!ok) { host_csr_free(&Ar); host_csr_free(&At); host_csr_free(&Qf); QPDO_EPRINT("matrix conversion failed"); goto fail; }
         QdevCsr a = {Ar.nrows, Ar.ncols, Ar.nnz, Ar.rp, Ar.ci, Ar.val};
         QdevCsr t = {At.nrows, At.ncols, At.nnz, At.rp, At.ci, At.val};
@@ -392,7 +433,9 @@ QPDOWorkspace *qpdo_setup(const QPDOData *data, const QPDOSettings *settings) {
                 free(arp); free(qrp); free(trp); free(tci); free(tval);
             }
         }
-        host_csr_free(&Ar); host_csr_free(&At); host_csr_free(&Qf);
+        if (prof) { fprintf(stderr, "[setup] device create     %.3f s (upload, slab tables)\n", wall_now() - t0); t0 = wall_now(); }
+        host_csr_free_async(&Ar, &At, &Qf);       /* unmapping several GB takes ~0.5 s: off the caller's path */
+        if (prof) { fprintf(stderr, "[setup] host free         %.3f s\n", wall_now() - t0); }
         if (rc) { QPDO_EPRINT("device backend: %s", qdev_last_error()); goto fail; }
         const char *ls = getenv("QPDO_LINSOLVE");
         int mode = -1;
@@ -409,7 +452,9 @@ QPDOWorkspace *qpdo_setup(const QPDOData *data, const QPDOSettings *settings) {
         work->scaling->Einv = calloc(m ? m : 1, sizeof(c_float));
         if (!work->scaling->D || !work->scaling->Dinv || !work->scaling->E || !work->scaling->Einv) goto fail;
         /* scale_data (scaling.c:24-91): A, Q, q on the device; l, u through the host mirrors */
+        const double ts0 = wall_now();
         if (qdev_scale_data(work->chol->dev, (int)settings->scaling, 0, work->scaling->D, work->scaling->E, &work->scaling->c)) goto fail_dev;
+        if (env_int("QPDO_SETUP_PROF", 0)) fprintf(stderr, "[setup] device scaling    %.3f s\n", wall_now() - ts0);
         if (install_scaling(work)) goto fail_dev;
         if (qdev_download_q(work->chol->dev, work->data->q)) goto fail_dev;
         for (size_t i = 0; i < m; i++) { work->data->l[i] = work->scaling->E[i] * work->data->l[i]; work->data->u[i] = work->scaling->E[i] * work->data->u[i]; }

@@ -304,6 +304,28 @@ def test_matrix_storage_variants_give_identical_results(gpu_required):
             assert np.array_equal(r["x"], base["x"]) and np.array_equal(r["y"], base["y"])
 
 
+def test_threaded_setup_conversions_give_identical_results(gpu_required, monkeypatch):
+    """qpdo_setup converts CSC -> CSR with several host threads (column ranges, per-thread row counts); the arrays
+    must be the ones the single-threaded counting pass produces: same bits out of the solve"""
+    import scipy.sparse as sp
+    p = problems.random_qp(52, 300, 500, 0.05, 20)
+    Qf = problems.full_Q(p)
+    base = None
+    for threads in ("1", "7", "16"):
+        monkeypatch.setenv("QPDO_SETUP_THREADS", threads)
+        for Qm, st in [(p["Q"], -1), (sp.triu(Qf).tocsc(), 1)]:
+            s = solver.QPDO().setup(Qm, p["q"], p["A"], p["l"], p["u"], Qstype=st, verbose=0)
+            y = s.spmv(0, np.arange(p["n"], dtype=float)); z = s.spmv(2, np.arange(p["n"], dtype=float))
+            r = s.solve()
+            s.delete()
+            if base is None:
+                base = (r, y, z)
+            else:
+                assert np.array_equal(y, base[1]) and np.array_equal(z, base[2])
+                assert r["info"]["iterations"] == base[0]["info"]["iterations"]
+                assert np.array_equal(r["x"], base[0]["x"]) and np.array_equal(r["y"], base[0]["y"])
+
+
 def test_problem_without_constraints(gpu_required, linsolve):
     """m = 0: the solve degenerates to (Q + sigma I) steps; every kernel must cope with empty m-vectors"""
     import scipy.sparse as sp
