@@ -247,6 +247,33 @@ def test_config2_full_size_properties(gpu_required):
     assert np.abs(r["y"][inside]).max() <= 1e-5
 
 
+def test_config4_full_size_properties(gpu_required):
+    """BASELINE.json metric configuration: n=1e5, m=2e5, 1 % fill (2e8 + 1e8 nonzeros, LDS-staged slab kernels over
+    the slab-major image, deflated Jacobi-PCG).  No oracle reaches this size; checked through size-independent
+    properties: the three products against scipy's CSC products on the same arrays, then a full cold-start solve:
+    status, independently recomputed KKT residuals, agreement with the reported norms, complementarity."""
+    p = problems.config_qp("C4")
+    s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0, scaling=0)
+    assert s.stats()["linsolve"] == 0
+    rng = np.random.default_rng(4)
+    xn, ym = rng.standard_normal(p["n"]), rng.standard_normal(p["m"])
+    Qf = problems.full_Q(p)
+    for which, M, v in ((0, p["A"], xn), (1, p["A"].T.tocsr(), ym), (2, Qf, xn)):
+        ref = M @ v
+        bound = abs(M) @ np.abs(v)
+        got = s.spmv(which, v)
+        assert np.all(np.abs(got - ref) <= 1e-13 * bound + 1e-300), which
+    s.delete()
+    r = solver.solve_problem(p, verbose=0)
+    assert r["info"]["status_val"] == 1
+    rp, rd = problems.kkt_residuals(p, r["x"], r["y"])
+    assert rp <= 1e-6 and rd <= 1e-6
+    assert abs(rp - r["info"]["res_prim_norm"]) <= 1e-9 and abs(rd - r["info"]["res_dual_norm"]) <= 1e-9
+    Ax = p["A"] @ r["x"]
+    inside = (Ax > p["l"] + 1e-5) & (Ax < p["u"] - 1e-5)
+    assert np.abs(r["y"][inside]).max() <= 1e-5
+
+
 @pytest.mark.parametrize("mode", ["fused", "threads"])
 def test_batch_of_mpc_sized_qps_matches_oracle(mode, gpu_required, monkeypatch):
     """BASELINE.json configs[2] (n=120, m=360 with equality rows), a slice of the batch, plus other small
