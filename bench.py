@@ -72,9 +72,11 @@ def allreduce(dist, vals, op="sum"):
     return t.tolist()
 
 
-def cpu_baseline(prob, seconds, cg_per_newton):
+def cpu_baseline(prob, seconds, cg_per_newton, cg_source):
     """Bounded sample on this host's cores: `seconds` of the oracle's Jacobi-PCG on the same matrices
-    (scaling off: the CG iteration cost does not depend on the scaling values), single thread."""
+    (scaling off: the CG iteration cost does not depend on the scaling values), single thread.  The oracle's
+    solver is plain Jacobi-PCG, so its rate is converted with the iterations per Newton pass that algorithm needs
+    (measured on the GPU with the same algorithm), not with the count of the GPU's Schur-complement mode."""
     from oracle import binding as ob
     s = ob.default_settings(scaling=0, max_time=seconds)
     o = ob.OracleSolver(prob, s, linsolve="pcg", pcg_tol=1e-12)
@@ -89,9 +91,9 @@ def cpu_baseline(prob, seconds, cg_per_newton):
     newton_rate = cg_rate / cg_per_newton if cg_per_newton > 0 else None
     return dict(value=newton_rate, unit="newton_iters/s", cores=1, kind="port",
                 sample=("%.1f s of the oracle's Jacobi-PCG on the same instance (scaling off, 1 thread): %d CG iterations "
-                        "= %.3f CG it/s, divided by the %.1f CG iterations per Newton pass the GPU run needed; the reference's "
+                        "= %.3f CG it/s, divided by the %.1f Jacobi-CG iterations per Newton pass (%s); the reference's "
                         "own direct CHOLMOD path is not buildable here and would need ~80 GB / 3.3e14 flop per factor at C4"
-                        % (dt, cg, cg_rate, cg_per_newton)),
+                        % (dt, cg, cg_rate, cg_per_newton, cg_source)),
                 cg_iters_per_s=cg_rate)
 
 
@@ -124,6 +126,8 @@ def main():
     iters = oters = 0
     statuses = []
     at_time = at_n = 0.0
+    ac_time = ac_bytes = ac_n = 0.0
+    schur_passes = 0
     for _ in range(a.steps):
         r = s.solve()
         stt = s.stats()
@@ -131,6 +135,7 @@ def main():
         iters += r["info"]["iterations"]; oters += r["info"]["oterations"]
         statuses.append(r["info"]["status_val"])
         at_time += stt["spmv_Q_avg_s"] * stt["spmv_Q_samples"]; at_n += stt["spmv_Q_samples"]
+        ac_time += stt["spmv_Ac_time_s"]; ac_bytes += stt["spmv_Ac_bytes"]; ac_n += stt["spmv_Ac_samples"]; schur_passes += stt["schur_passes"]
     L.qpdo_amd_sync(s._w)
     barrier(dist)
     dt = time.time() - t0
@@ -141,26 +146,44 @@ def main():
 
     last = r
     rp, rd = problems.kkt_residuals(prob, last["x"], last["y"]) if last["info"]["status_val"] not in (-3, -4) else (None, None)
-    # roofline of the dominant kernel: the Q product of the PCG operator (k_spmv_slab<EpiPcgQ>, full symmetric
-    # CSR n x n; the A and A' products of PCG only touch the active rows / columns, so Q carries the most bytes).
-    # Live HIP-event samples from the timed solves; a back-to-back micro-benchmark of the same kernel beside it.
-    bench_t, alg_bytes = s.bench_spmv(2, reps=20)
-    live_t = at_time / at_n if at_n else bench_t
-    achieved = alg_bytes / live_t / 1e9
-    roof = dict(bound="hbm", kernel="k_spmv_slab<EpiPcgQ> (Kp = Q p + sigma p, full symmetric CSR n x n)", achieved=achieved, peak=HBM_PEAK_GBS,
-                unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None, alg_bytes_per_launch=alg_bytes,
-                avg_launch_s=live_t, samples=int(at_n), microbench_GBs=alg_bytes / bench_t / 1e9,
-                spmv_A_GBs=None, spmv_At_GBs=None)
-    # HBM bytes per launch from the PMC counters cannot be collected inside this process; the figure comes from
-    # the committed rocprofv3 --pmc passes on the same workload and kernel (profiles/r01_pmc_spmv_c4.json), if present
+    # roofline of the dominant kernel, live HIP-event samples from the timed solves.  With the Schur-complement mode
+    # of the PCG the bulk of the time is the inner solves' A_c product (k_spmv_slab<EpiSchurA>: the k active rows of A,
+    # compact index space, k changes per pass, so bytes and time are summed over the samples); otherwise it is the Q
+    # product of the PCG operator (k_spmv_slab<EpiPcgQ>).  A back-to-back micro-benchmark of the full-size kernel beside it.
+    pmc = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_spmv_c4.json")) as fh:
             pmc = json.load(fh)
-        if a.workload == "C4":
-            roof["traffic"] = pmc["Q  (CSR n x n)"]["traffic_bytes"]
-            roof["traffic_source"] = "profiles/r01_pmc_spmv_c4.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
     except Exception:
         pass
+    if ac_n > at_n and ac_time > 0:
+        bench_t, full_bytes = s.bench_spmv(0, reps=20)
+        achieved = ac_bytes / ac_time / 1e9
+        roof = dict(bound="hbm", kernel="k_spmv_slab<EpiSchurA> (S'p = p/d + A_c t: the active rows of A in the pass's compact index space)",
+                    achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
+                    alg_bytes_per_launch=ac_bytes / ac_n, avg_launch_s=ac_time / ac_n, samples=int(ac_n),
+                    microbench_GBs=full_bytes / bench_t / 1e9, spmv_A_GBs=None, spmv_At_GBs=None)
+        if pmc is not None and a.workload == "C4":
+            ratio = pmc["A  (CSR m x n)"]["traffic_over_alg"]
+            roof["traffic"] = ratio * ac_bytes / ac_n
+            roof["traffic_source"] = ("profiles/r01_pmc_spmv_c4.json: measured HBM bytes / algorithmic bytes = %.3f for the same kernel on the full A "
+                                      "(2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes), applied to the average compact launch" % ratio)
+        if at_n:
+            q_t, q_b = s.bench_spmv(2, reps=5)
+            roof["spmv_Q_live_GBs"] = q_b / (at_time / at_n) / 1e9
+    else:
+        bench_t, alg_bytes = s.bench_spmv(2, reps=20)
+        live_t = at_time / at_n if at_n else bench_t
+        achieved = alg_bytes / live_t / 1e9
+        roof = dict(bound="hbm", kernel="k_spmv_slab<EpiPcgQ> (Kp = Q p + sigma p, full symmetric CSR n x n)", achieved=achieved, peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None, alg_bytes_per_launch=alg_bytes,
+                    avg_launch_s=live_t, samples=int(at_n), microbench_GBs=alg_bytes / bench_t / 1e9,
+                    spmv_A_GBs=None, spmv_At_GBs=None)
+        # HBM bytes per launch from the PMC counters cannot be collected inside this process; the figure comes from
+        # the committed rocprofv3 --pmc passes on the same workload and kernel (profiles/r01_pmc_spmv_c4.json), if present
+        if pmc is not None and a.workload == "C4":
+            roof["traffic"] = pmc["Q  (CSR n x n)"]["traffic_bytes"]
+            roof["traffic_source"] = "profiles/r01_pmc_spmv_c4.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
     for which, key in ((0, "spmv_A_GBs"), (1, "spmv_At_GBs")):
         t_, b_ = s.bench_spmv(which, reps=20)
         roof[key] = b_ / t_ / 1e9
@@ -178,7 +201,7 @@ def main():
                                    "default settings (eps_abs=1e-6, scaling=10)%s" % (
                                        a.workload, cfg["n"], cfg["m"], cfg["density"],
                                        (", max_time=%gs" % a.max_time) if a.max_time > 0 else ""),
-                       "n": cfg["n"], "m": cfg["m"], "density": cfg["density"], "linsolve": "jacobi-pcg" if s.stats()["linsolve"] == 0 else "dense-ldlt",
+                       "n": cfg["n"], "m": cfg["m"], "density": cfg["density"], "linsolve": ("pcg: Jacobi + heavy-row deflation, Schur-complement mode on %d of %d Newton passes" % (schur_passes, newton)) if s.stats()["linsolve"] == 0 else "dense-ldlt",
                        "parallelism": ("one QP, rows of A partitioned over the GPUs, RCCL all-reduce of A'y" if rows_mode
                                        else "independent QPs per GPU, no collective")},
             "time_to_eps_s": dt_max / max(1, a.steps) if all(v == 1 for v in statuses) else None,
@@ -188,9 +211,17 @@ def main():
             "roofline": roof,
         }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cgpn = (cg / newton) if newton else 0.0
+        cgpn, src = (cg / newton) if newton else 0.0, "this GPU run"
+        if schur_passes:      # the GPU count is not the CPU algorithm's: use the committed Jacobi-only GPU run of the same instance
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_c4_jacobi_reference.json")) as fh:
+                    jr = json.load(fh)
+                if jr.get("workload") == a.workload:
+                    cgpn, src = jr["cg_iters"] / jr["newton_passes"], "profiles/r01_c4_jacobi_reference.json: deflated Jacobi-PCG on the GPU, same instance"
+            except Exception:
+                pass
         try:
-            out["cpu_baseline"] = cpu_baseline(prob, a.cpu_seconds, cgpn)
+            out["cpu_baseline"] = cpu_baseline(prob, a.cpu_seconds, cgpn, src)
         except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU line
             out["cpu_baseline"] = dict(value=None, unit="newton_iters/s", cores=1, kind="port", sample="failed: %r" % (e,))
     s.delete()

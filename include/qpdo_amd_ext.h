@@ -17,6 +17,7 @@
  *   QPDO_SPMV        "slab" | "plain" (default: LDS-staged slab kernel for matrices >= 192 MB)
  *   QPDO_DEFLATE     "0" disables the heavy-row deflation of the PCG preconditioner
  *   QPDO_IDX16       "0" disables the 16-bit slab-local column indices
+ *   QPDO_PCG_SCHUR   "0" disables / "1" forces the Schur-complement mode of the PCG (default: automatic)
  *   QPDO_PCG_TOL     relative residual tolerance of the Jacobi-PCG solve (default 1e-12)
  *   QPDO_PCG_MAXIT   PCG iteration cap per Newton step (default 100000)
  *   QPDO_FIX_STATUS_RESET  "1": reset info->status_val at the start of qpdo_solve
@@ -51,6 +52,10 @@ typedef struct {
     long   linsolve;        /* 0 pcg, 1 dense                                              */
     double spmv_Q_avg_s;    /* HIP-event average duration of the sampled Q SpMV inside PCG */
     long   spmv_Q_samples;
+    double spmv_Ac_time_s;  /* Schur-mode inner solves: summed HIP-event time of the sampled A_c products ...          */
+    double spmv_Ac_bytes;   /* ... and their summed algorithmic bytes (compact matrix, size changes per pass)          */
+    long   spmv_Ac_samples;
+    long   schur_passes;    /* Newton passes solved by the Schur-complement mode of the PCG                            */
     long   lowrank_solves;  /* dense solves through the low-rank update of the kept factor (cholmod_interface.c:57-93) */
     long   lowrank_cols;    /* rows that entered the low-rank set (one multi-RHS solve column each)                 */
     long   lowrank_sweeps;  /* refinement sweeps of the low-rank solves (one kept-factor solve + 3 SpMV each)        */

@@ -794,6 +794,8 @@ int qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out) {
     out->linsolve = st.linsolve;
     out->spmv_Q_avg_s = avg;
     out->spmv_Q_samples = ns;
+    { double ts = 0, bs = 0; long n2 = 0, sp = 0; qdev_get_ac_sample(work->chol->dev, &ts, &bs, &n2, &sp);
+      out->spmv_Ac_time_s = ts; out->spmv_Ac_bytes = bs; out->spmv_Ac_samples = n2; out->schur_passes = sp; }
     out->lowrank_solves = (long)st.lowrank_solves;
     out->lowrank_cols = (long)st.lowrank_cols;
     out->lowrank_sweeps = (long)st.lowrank_sweeps;

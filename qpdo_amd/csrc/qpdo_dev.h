@@ -127,6 +127,8 @@ int qdev_get_stats(QpdoDev *d, QdevStats *out);
 int qdev_reset_stats(QpdoDev *d);
 /* HIP-event average of the Q SpMV sampled once per PCG batch during the last solve */
 int qdev_get_spmv_sample(QpdoDev *d, double *avg_seconds, long *samples);
+/* HIP-event samples of the A_c product inside the Schur-mode inner solves: summed seconds and algorithmic bytes */
+int qdev_get_ac_sample(QpdoDev *d, double *seconds_sum, double *bytes_sum, long *samples, long *schur_passes);
 
 /* micro-benchmark of the dominant kernel on the workspace's own matrices, timed with HIP
  * events on the backend stream.  which: 0 A (CSR m x n), 1 A' (CSR n x m), 2 Q.

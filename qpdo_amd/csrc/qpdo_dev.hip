@@ -47,7 +47,7 @@ static int set_err(hipError_t e, const char *what, int line) {
 // ------------------------------------------------------------------------------------------------
 enum { N_PRIM = 0, N_DUAL, N_PRIM_IN, N_DUAL_IN, N_A, N_B, N_C, N_D, N_COUNT };
 enum { C_ACTIVE = 0, C_ENTER, C_LEAVE, C_NL, C_KSTAR, C_MUCH, C_VIOL, C_PCG_DONE, C_PCG_IT, C_CHAIN_ERR, C_COUNT = 12 };
-enum { V_TAU = 0, V_A0, V_B0, V_RZ, V_BNORM, V_OOB, V_QDX, V_OBJ, V_F, V_RR, V_COUNT = 16 };
+enum { V_TAU = 0, V_A0, V_B0, V_RZ, V_BNORM, V_OOB, V_QDX, V_OBJ, V_F, V_RR, V_RNORM, V_COUNT = 16 };
 struct Ctrl {
     u64 nrm[N_COUNT];      // non-negative doubles as bit patterns: atomicMax is exact and order free
     int cnt[C_COUNT];
@@ -131,6 +131,10 @@ struct QpdoDev {
     // control
     Ctrl *ctrl = nullptr;    // device
     Ctrl *hctrl = nullptr;   // pinned host
+    // Schur-complement mode of the PCG (pcg_solve): inner CG on S' = D^-1 + A_c Dq^-1 A_c' with its own control block
+    Ctrl *ctrl2 = nullptr, *hctrl2 = nullptr; double *part2 = nullptr;
+    double *s_x = nullptr, *s_r = nullptr, *s_z = nullptr, *s_p = nullptr, *s_Sp = nullptr, *s_diag = nullptr, *s_v = nullptr;
+    int schur_mode = -1 /* -1 auto, 0 off, 1 on */, schur_off = 0, schur_strikes = 0, last_jacobi_iters = 0; long long schur_passes = 0;
     double *part = nullptr;  // P_COUNT * PGRID
     // scaling
     int scaled = 0; double sc_c = 1.0, sc_cinv = 1.0;
@@ -142,6 +146,7 @@ struct QpdoDev {
     QdevStats st{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double ev_spmv_ms = 0.0; long long ev_spmv_n = 0;
+    double ev_ac_ms = 0.0, ev_ac_bytes = 0.0; long long ev_ac_n = 0;      // sampled A_c products of the Schur mode's inner solve
     std::vector<void *> allocs;
 };
 
@@ -514,6 +519,21 @@ struct EpiPcgAt {                          // Kp += A' t ; partial p.Kp
         if (threadIdx.x == 0) p_pKp[blockIdx.x] = t;
     }
 };
+struct EpiDivStore {                       // out = (M x) ./ w
+    const double *w; double *out;
+    __device__ bool skip(int) const { return false; }
+    __device__ void row(int r, double s) { out[r] = s / w[r]; }
+    __device__ void finish(double *) {}
+};
+struct EpiSchurA {                         // Sp = p ./ d + A_c t ; partial p.Sp   (S' = D^-1 + A_c Dq^-1 A_c')
+    const double *dc, *p; double *Sp, *p_pSp; double acc = 0.0;
+    __device__ bool skip(int) const { return false; }
+    __device__ void row(int r, double s) { const double v = p[r] / dc[r] + s; Sp[r] = v; acc += p[r] * v; }
+    __device__ void finish(double *sm) {
+        double t = block_sum(acc, sm);
+        if (threadIdx.x == 0) p_pSp[blockIdx.x] = t;
+    }
+};
 struct EpiResid {                          // r = rhs - (Kp + A' t), ||r||inf -> ctrl->nrm[slot] (inf if any NaN)
     const double *rhs, *Kp; double *r; Ctrl *ctrl; int slot; double mx = 0.0;
     __device__ bool skip(int) const { return false; }
@@ -602,9 +622,9 @@ __global__ __launch_bounds__(256) void k_spmv_pcg(const int *__restrict__ done, 
     epi.finish(sm);
 }
 template <class Epi>
-static void launch_spmv_pcg(QpdoDev *d, const DevCsr &M, const double *x, Epi epi, bool partials) {
+static void launch_spmv_pcg(QpdoDev *d, const DevCsr &M, const double *x, Epi epi, bool partials, const int *latch = nullptr) {
     const int g = spmv_grid(M, M.tpr, partials);
-    const int *done = &d->ctrl->cnt[C_PCG_DONE];
+    const int *done = latch ? latch : &d->ctrl->cnt[C_PCG_DONE];
     if (M.use_slab) { launch_spmv_slab(d, M, x, epi, done); return; }
     switch (M.tpr) {
         case 4:  hipLaunchKernelGGL((k_spmv_pcg<4, Epi>),  dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
@@ -710,6 +730,20 @@ __global__ __launch_bounds__(256) void k_jacobi_diag2(int n, const int *__restri
             const double rem = qdiag[row] + sigma_f + s, full = qdiag[row] + sigma_f + f;
             out[row] = rem > 1e-6 * full ? rem : 1e-6 * full;
         }
+    }
+}
+// diagonal of the inner system of the Schur mode: Sd_i = 1/d_i + sum_j A_ij^2 / Dq_j  (row i of the compact A_c)
+template <int TPR>
+__global__ __launch_bounds__(256) void k_schur_diag(int k, const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
+                                                    const double *__restrict__ Dq, const double *__restrict__ dc, double *__restrict__ out) {
+    const int lane = threadIdx.x % TPR;
+    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
+    const int ngroups = gridDim.x * (BLK / TPR);
+    for (int row = group; row < k; row += ngroups) {
+        double s = 0.0;
+        for (int e = rp[row] + lane; e < rp[row + 1]; e += TPR) { const double v = val[e]; s += v * v / Dq[ci[e]]; }
+        s = group_sum<TPR>(s);
+        if (lane == 0) out[row] = 1.0 / dc[row] + s;
     }
 }
 __global__ void k_extract_diag(int n, const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
@@ -1234,6 +1268,7 @@ __global__ __launch_bounds__(256) void k_pcg_scalar(Ctrl *ctrl, const double *__
     const double rz2 = reduce_partials(p_rz, cnt_rz, sm), rr = reduce_partials(p_rr, cnt, sm + 16);
     if (threadIdx.x == 0) {
         ctrl->cnt[C_PCG_IT] += 1;
+        ctrl->val[V_RNORM] = sqrt(rr);
         if (sqrt(rr) <= tol * ctrl->val[V_BNORM] || !(rr == rr)) ctrl->cnt[C_PCG_DONE] = 1;
         ctrl->val[V_RR] = rz2 / ctrl->val[V_RZ];     // beta
         ctrl->val[V_RZ] = rz2;
@@ -2358,8 +2393,11 @@ int qdev_create_dist(QpdoDev **out, int device, int32_t n, int32_t m, const Qdev
     d->ls_nblk = (int)((M2 + LS_TILE - 1) / LS_TILE); if (d->ls_nblk < 1) d->ls_nblk = 1;
     A_(ls_bt, (size_t)2 * d->ls_nblk + 2);
     A_(ctrl, 1); A_(part, (size_t)P_COUNT * PGRID);
+    A_(ctrl2, 1); A_(part2, (size_t)3 * PGRID);
+    A_(s_x, m); A_(s_r, m); A_(s_z, m); A_(s_p, m); A_(s_Sp, m); A_(s_diag, m); A_(s_v, m);
 #undef A_
     if (!rc) { e = hipHostMalloc((void **)&d->hctrl, sizeof(Ctrl), hipHostMallocDefault); if (e != hipSuccess) rc = set_err(e, "hipHostMalloc", __LINE__); }
+    if (!rc) { e = hipHostMalloc((void **)&d->hctrl2, sizeof(Ctrl), hipHostMallocDefault); if (e != hipSuccess) rc = set_err(e, "hipHostMalloc", __LINE__); }
     if (!rc) { e = hipEventCreate(&d->ev0); if (e == hipSuccess) e = hipEventCreate(&d->ev1); if (e != hipSuccess) rc = set_err(e, "hipEventCreate", __LINE__); }
     if (!rc) {
         e = hipMemcpyAsync(d->q, q, (size_t)n * 8, hipMemcpyHostToDevice, d->stream);
@@ -2441,6 +2479,7 @@ void qdev_destroy(QpdoDev *d) {
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     for (void *p : d->allocs) (void)hipFree(p);
     if (d->hctrl) (void)hipHostFree(d->hctrl);
+    if (d->hctrl2) (void)hipHostFree(d->hctrl2);
     if (d->comm.hbuf) (void)hipHostFree(d->comm.hbuf);
     if (d->comm.nccl) ncclCommDestroy(d->comm.nccl);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -2457,6 +2496,8 @@ int qdev_configure(QpdoDev *d, int linsolve, double pcg_tol, int pcg_maxit) {
     if (gr && !strcmp(gr, "0")) d->pcg_graph = 0;
     const char *mx = getenv("QPDO_DENSE_MAX_N");
     if (mx && *mx) d->dense_max_n = atoi(mx);
+    const char *sc = getenv("QPDO_PCG_SCHUR");
+    if (sc && *sc) d->schur_mode = atoi(sc) != 0;
     const char *ch = getenv("QPDO_DENSE_SOLVE");
     if (ch && !strcmp(ch, "steps")) d->dense_chain = 0;
     const char *lr = getenv("QPDO_DENSE_LOWRANK");
@@ -2473,12 +2514,16 @@ int qdev_configure(QpdoDev *d, int linsolve, double pcg_tol, int pcg_maxit) {
     return 0;
 }
 int qdev_get_stats(QpdoDev *d, QdevStats *out) { *out = d->st; return 0; }
+int qdev_get_ac_sample(QpdoDev *d, double *seconds_sum, double *bytes_sum, long *samples, long *schur_passes) {
+    *seconds_sum = d->ev_ac_ms * 1e-3; *bytes_sum = d->ev_ac_bytes; *samples = (long)d->ev_ac_n; *schur_passes = (long)d->schur_passes;
+    return 0;
+}
 int qdev_get_spmv_sample(QpdoDev *d, double *avg_seconds, long *samples) {
     *samples = (long)d->ev_spmv_n;
     *avg_seconds = d->ev_spmv_n ? d->ev_spmv_ms * 1e-3 / (double)d->ev_spmv_n : 0.0;
     return 0;
 }
-int qdev_reset_stats(QpdoDev *d) { int ls = d->st.linsolve; d->st = QdevStats{}; d->st.linsolve = ls; d->ev_spmv_ms = 0; d->ev_spmv_n = 0; return 0; }
+int qdev_reset_stats(QpdoDev *d) { int ls = d->st.linsolve; d->st = QdevStats{}; d->st.linsolve = ls; d->ev_spmv_ms = 0; d->ev_spmv_n = 0; d->ev_ac_ms = 0; d->ev_ac_bytes = 0; d->ev_ac_n = 0; d->schur_passes = 0; return 0; }
 
 // ---- scaling (scaling.c:24-91) ------------------------------------------------------------------
 int qdev_scale_data(QpdoDev *d, int iters, int use_Qx, double *D_host, double *E_host, double *c_out) {
@@ -2651,6 +2696,7 @@ int qdev_warm_start(QpdoDev *d, const double *x_ws, const double *y_ws, int prox
 }
 int qdev_begin_solve(QpdoDev *d) {
     HIPCHK(hipSetDevice(d->device));
+    d->last_jacobi_iters = 0; d->schur_off = 0; d->schur_strikes = 0;
     if (d->m) HIPCHK(hipMemsetAsync(d->active_old, 0, (size_t)d->m * sizeof(int), d->stream));
     return 0;
 }
@@ -2815,6 +2861,120 @@ static int defl_apply(QpdoDev *d, const int *done, double *p_rz) {
     d->st.spmv_calls--; d->st.spmv_bytes -= (int64_t)d->Ath.alg_bytes();     // not one of the big products
     return spmv_pgrid(d->Ath);
 }
+// ---- Schur-complement mode of the PCG ---------------------------------------------------------------------
+// Late in a solve the weights d = 1/mu of the active rows spread over 2^8..2^16 and Jacobi-PCG on
+// K = Q~ + A_c' D A_c needs 1000+ iterations per pass (kappa ~ spread x the Marchenko-Pastur ratio of A_c).
+// Preconditioner M = Dq + A_c' D A_c with Dq = diag(Q~): it treats the whole penalty term exactly, so M^-1 K =
+// I + M^-1 offdiag(Q) and the outer CG converges in ~10 iterations when Q is diagonally dominant in the spectral
+// sense.  M^-1 r = u - Dq^-1 A_c' s,  u = Dq^-1 r,  S' s = A_c u,  S' = D^-1 + A_c Dq^-1 A_c'  (k x k, never formed):
+// the inner system is solved by Jacobi-PCG; its conditioning is that of A_c Dq^-1 A_c' (Marchenko-Pastur,
+// ((1+sqrt(k/n))/(1-sqrt(k/n)))^2 ~ 160 at k/n = 0.73) and does NOT depend on the spread of d; its products are two
+// SpMV with the compact matrices and no Q product.  Measured on the C2 system of the last pass (numpy prototype):
+// 1862 Jacobi iterations (5586 SpMV) -> 11 outer x 78 inner (1777 SpMV, none of them Q).  The inner solve must be
+// tight (1e-6): at 1e-3 the outer iteration degrades to hundreds of steps even with a flexible beta.
+// Used when k/n <= 0.8 (beyond that the inner conditioning explodes) and the previous Jacobi pass was slow.
+static int read_ctrl2(QpdoDev *d) {
+    HIPCHK(hipMemcpyAsync(d->hctrl2, d->ctrl2, sizeof(Ctrl), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+static const int SCHUR_INNER_MAXIT = 4000, SCHUR_OUTER_MAXIT = 40;
+// s_x = S'^-1 s_v by Jacobi-PCG (device latch in ctrl2, batches of iterations between host syncs)
+static int schur_inner_solve(QpdoDev *d, double tol, int *iters) {
+    const int k = d->kact, g = vgrid(k);
+    double *P2 = d->part2;                   // slots: 0 p.Sp, 1 r.z, 2 r.r
+    const int *done2 = &d->ctrl2->cnt[C_PCG_DONE];
+    LAUNCH(k_pcg_init, g, k, (const double *)d->s_v, (const double *)d->s_diag, d->s_x, d->s_r, d->s_z, d->s_p, P2 + 1 * PGRID, P2 + 2 * PGRID);
+    LAUNCH(k_pcg_init2, 1, (const double *)(P2 + 1 * PGRID), g, (const double *)(P2 + 2 * PGRID), g, d->ctrl2);
+    const int pcnt = spmv_pgrid(d->Arc);
+    int it = 0;
+    while (it < SCHUR_INNER_MAXIT) {
+        const int it_before = it;
+        for (int b = 0; b < d->pcg_batch; b++) {
+            launch_spmv_pcg(d, d->Atc, d->s_p, EpiDivStore{d->pc_diag, d->tmp_n}, false, done2);
+            if (b == 0) (void)hipEventRecord(d->ev0, d->stream);      // HIP-event sample of the dominant kernel, one per batch
+            launch_spmv_pcg(d, d->Arc, d->tmp_n, EpiSchurA{d->dc, d->s_p, d->s_Sp, P2}, true, done2);
+            if (b == 0) (void)hipEventRecord(d->ev1, d->stream);
+            LAUNCH(k_pcg_update, g, k, (const Ctrl *)d->ctrl2, (const double *)P2, pcnt, (const double *)d->s_p, (const double *)d->s_Sp,
+                   (const double *)d->s_diag, d->s_x, d->s_r, d->s_z, P2 + 1 * PGRID, P2 + 2 * PGRID);
+            LAUNCH(k_pcg_scalar, 1, d->ctrl2, (const double *)(P2 + 1 * PGRID), g, (const double *)(P2 + 2 * PGRID), g, tol);
+            LAUNCH(k_pcg_p, g, k, (const Ctrl *)d->ctrl2, (const double *)d->s_z, d->s_p);
+        }
+        it += d->pcg_batch;
+        int rc = read_ctrl2(d); if (rc) return rc;
+        if (d->hctrl2->cnt[C_PCG_IT] > it_before) {          // the sampled (first) iteration of this batch really ran
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, d->ev0, d->ev1) == hipSuccess) { d->ev_ac_ms += ms; d->ev_ac_bytes += d->Arc.alg_bytes(); d->ev_ac_n++; }
+        }
+        if (d->hctrl2->cnt[C_PCG_DONE]) break;
+    }
+    *iters = d->hctrl2->cnt[C_PCG_IT];
+    return d->hctrl2->cnt[C_PCG_DONE] ? 0 : 1;          // 1: not converged
+}
+// z <- M^-1 r given u = Dq^-1 r in pc_z; leaves the r.z partials in p_rz.  Returns their count (or -1 on failure).
+static int schur_apply(QpdoDev *d, double tol, double *p_rz, int *inner_iters, int *status) {
+    launch_spmv(d, d->Arc, d->pc_z, EpiStore{d->s_v}, false);
+    int it = 0;
+    *status = schur_inner_solve(d, tol, &it);
+    *inner_iters += it;
+    if (*status < 0) return -1;
+    launch_spmv(d, d->Atc, d->s_x, EpiDeflZ{d->pc_diag, d->pc_r, d->pc_z, p_rz}, true);
+    return spmv_pgrid(d->Atc);
+}
+// K dx = rhs with the Schur-preconditioned outer CG.  *fallback = 1: did not converge, the caller reruns Jacobi-PCG.
+static int pcg_schur_solve(QpdoDev *d, int *iters_out, int *fallback) {
+    const int n = d->n, k = d->kact, g = vgrid(n);
+    double *P = d->part;
+    *fallback = 0;
+    LAUNCH(k_axpy_const, g, n, (const double *)d->qdiag, d->sigma_f, d->pc_diag);                  // Dq
+    DISPATCH_TPR(d->Ar, k_schur_diag, (d->Ar.use_slab ? 2048 : spmv_grid(d->Ar, d->Ar.tpr, false)), k, d->Arc.rp, d->Arc.ci, d->Arc.val,
+                 (const double *)d->pc_diag, (const double *)d->dc, d->s_diag);
+    // Inner tolerance.  An inner residual rho leaves M z - r = A_c' D rho: the error that matters is weighted by D, so
+    // the tolerance must shrink with the largest weight (tau = 1e-6 sufficed on every C4 pass with dmax <= 5e3 and
+    // failed at dmax = 7e5).  It is also tightened on the fly whenever an outer step reduces the residual by less than 4x.
+    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
+    LAUNCH(k_absmax_mul, vgrid(k), k, (const double *)d->dc, (const double *)nullptr, d->ctrl, N_A);
+    LAUNCH(k_pcg_init, g, n, d->rhs, d->pc_diag, d->dx, d->pc_r, d->pc_z, d->pc_p, P + P_RZ * PGRID, P + P_RR * PGRID);
+    { int rc0 = read_ctrl(d); if (rc0) return rc0; }
+    const double dmax = nrm_of(d->hctrl, N_A);
+    double tau = 1e-6 * (dmax > 1e4 ? 1e4 / dmax : 1.0);
+    if (tau < 1e-13) tau = 1e-13;
+    int inner = 0, st = 0;
+    int cnt_rz = schur_apply(d, tau, P + P_RZ * PGRID, &inner, &st);
+    if (cnt_rz < 0) return -1;
+    if (st) { *fallback = 1; return 0; }
+    LAUNCH(k_copy, g, n, (const double *)d->pc_z, d->pc_p);
+    LAUNCH(k_pcg_init2, 1, P + P_RZ * PGRID, cnt_rz, P + P_RR * PGRID, g, d->ctrl);
+    const int pKp_cnt = spmv_pgrid(d->Atc);
+    int outer = 0;
+    double prev_rn = -1.0;
+    for (;;) {
+        int rc = read_ctrl(d); if (rc) return rc;
+        if (d->hctrl->cnt[C_PCG_DONE]) break;
+        if (outer > 0) {
+            const double rn = d->hctrl->val[V_RNORM];
+            if (prev_rn > 0.0 && rn > 0.25 * prev_rn && tau > 1e-13) { tau *= 1e-2; if (tau < 1e-13) tau = 1e-13; }
+            prev_rn = rn;
+        }
+        if (outer >= SCHUR_OUTER_MAXIT) { if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[schur] k=%d outer cap reached (inner=%d)\n", k, inner); *fallback = 1; return 0; }
+        launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
+        launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQ{d->pc_p, d->sigma_f, d->pc_Kp}, false);
+        launch_spmv_pcg(d, d->Atc, d->tc, EpiPcgAt{d->pc_p, d->pc_Kp, P + P_PKP * PGRID}, true);
+        LAUNCH(k_pcg_update, g, n, (const Ctrl *)d->ctrl, (const double *)(P + P_PKP * PGRID), pKp_cnt, (const double *)d->pc_p, (const double *)d->pc_Kp,
+               (const double *)d->pc_diag, d->dx, d->pc_r, d->pc_z, P + P_RZ * PGRID, P + P_RR * PGRID);
+        cnt_rz = schur_apply(d, tau, P + P_RZ * PGRID, &inner, &st);
+        if (cnt_rz < 0) return -1;
+        if (st) { if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[schur] k=%d inner solve did not converge (outer=%d inner=%d)\n", k, outer, inner); *fallback = 1; return 0; }
+        LAUNCH(k_pcg_scalar, 1, d->ctrl, (const double *)(P + P_RZ * PGRID), cnt_rz, (const double *)(P + P_RR * PGRID), g, d->pcg_tol);
+        LAUNCH(k_pcg_p, g, n, (const Ctrl *)d->ctrl, (const double *)d->pc_z, d->pc_p);
+        outer++;
+    }
+    if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[schur] dmax=%.2e tau_end=%.1e ", dmax, tau);
+    *iters_out = outer + inner;
+    d->schur_passes++;
+    if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[schur] k=%d outer=%d inner=%d\n", k, outer, inner);
+    return 0;
+}
 static int pcg_solve(QpdoDev *d, int *iters_out) {
     const int n = d->n;
     if (!d->qdiag_valid) {
@@ -2823,6 +2983,16 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
     }
     int rc = build_compact(d); if (rc) return rc;
     const int k = d->kact;
+    {   // Schur-complement mode: when the last Jacobi pass was slow and the inner system is well conditioned
+        const bool allowed = d->comm.world == 1 && !d->schur_off && d->schur_mode != 0 && k >= 256 && (double)k <= 0.8 * (double)n;
+        const bool wanted = d->schur_mode == 1 || d->last_jacobi_iters > 400;
+        if (allowed && wanted) {
+            int fb = 0;
+            rc = pcg_schur_solve(d, iters_out, &fb); if (rc) return rc;
+            if (!fb) return 0;
+            if (++d->schur_strikes >= 2) d->schur_off = 1;      // did not converge twice: plain path from here on
+        }
+    }
     rc = defl_build(d); if (rc) return rc;
     const bool defl = d->defl_r > 0;
     const bool dist = d->comm.world > 1;
@@ -2922,6 +3092,7 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
     if (graph) (void)hipGraphDestroy(graph);
     if (rc) return rc;
     *iters_out = d->hctrl->cnt[C_PCG_IT];
+    d->last_jacobi_iters = *iters_out;
     if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[pcg] k=%d defl_r=%d iters=%d\n", k, d->defl_r, *iters_out);
     return 0;
 }

@@ -89,7 +89,8 @@ class Stats(C.Structure):
     _fields_ = [("newton_passes", C.c_long), ("lin_iters", C.c_long), ("spmv_calls", C.c_long),
                 ("spmv_alg_bytes", C.c_double), ("factor_count", C.c_long), ("linsolve", C.c_long),
                 ("spmv_Q_avg_s", C.c_double), ("spmv_Q_samples", C.c_long),
-                ("lowrank_solves", C.c_long), ("lowrank_cols", C.c_long), ("lowrank_sweeps", C.c_long),
+                ("spmv_Ac_time_s", C.c_double), ("spmv_Ac_bytes", C.c_double), ("spmv_Ac_samples", C.c_long),
+                ("schur_passes", C.c_long), ("lowrank_solves", C.c_long), ("lowrank_cols", C.c_long), ("lowrank_sweeps", C.c_long),
                 ("lowrank_rejects", C.c_long)]
 
 
