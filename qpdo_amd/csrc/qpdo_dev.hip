@@ -2872,7 +2872,8 @@ static int defl_apply(QpdoDev *d, const int *done, double *p_rz) {
 // SpMV with the compact matrices and no Q product.  Measured on the C2 system of the last pass (numpy prototype):
 // 1862 Jacobi iterations (5586 SpMV) -> 11 outer x 78 inner (1777 SpMV, none of them Q).  The inner solve must be
 // tight (1e-6): at 1e-3 the outer iteration degrades to hundreds of steps even with a flexible beta.
-// Used when k/n <= 0.8 (beyond that the inner conditioning explodes) and the previous Jacobi pass was slow.
+// Used when 256 <= k <= 0.8 n (beyond that ratio the inner conditioning explodes); falls back to the deflated
+// Jacobi-PCG below when the outer iteration does not converge within SCHUR_OUTER_MAXIT steps (twice: off for the solve).
 static int read_ctrl2(QpdoDev *d) {
     HIPCHK(hipMemcpyAsync(d->hctrl2, d->ctrl2, sizeof(Ctrl), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
@@ -2983,10 +2984,11 @@ static int pcg_solve(QpdoDev *d, int *iters_out) {
     }
     int rc = build_compact(d); if (rc) return rc;
     const int k = d->kact;
-    {   // Schur-complement mode: when the last Jacobi pass was slow and the inner system is well conditioned
+    {   // Schur-complement mode whenever its inner system is well conditioned (k/n <= 0.8) and worth the set-up (k >= 256);
+        // it also wins on the early passes (uniform weights): fewer products and almost none of them with Q
+        // (C4: 9.2 s when used only after a slow Jacobi pass, 8.8 s when used from the first pass on)
         const bool allowed = d->comm.world == 1 && !d->schur_off && d->schur_mode != 0 && k >= 256 && (double)k <= 0.8 * (double)n;
-        const bool wanted = d->schur_mode == 1 || d->last_jacobi_iters > 400;
-        if (allowed && wanted) {
+        if (allowed) {
             int fb = 0;
             rc = pcg_schur_solve(d, iters_out, &fb); if (rc) return rc;
             if (!fb) return 0;
