@@ -232,6 +232,24 @@ def test_dense_chained_solve_matches_stepwise(gpu_required, monkeypatch):
     o.close()
 
 
+def test_pcg_schur_mode_matches_jacobi_and_oracle(gpu_required, monkeypatch):
+    """the Schur-complement mode of the PCG (outer CG preconditioned by Dq + A_c' D A_c, inner CG on the k x k
+    system) solves the same Newton systems as the deflated Jacobi-PCG: same pass counts, same iterates"""
+    monkeypatch.setenv("QPDO_LINSOLVE", "pcg")
+    p = problems.random_qp(61, 700, 1400, 0.03, 0)
+    monkeypatch.setenv("QPDO_PCG_SCHUR", "0")
+    r0 = solver.solve_problem(p, verbose=0)
+    monkeypatch.setenv("QPDO_PCG_SCHUR", "1")
+    r1 = solver.solve_problem(p, verbose=0)
+    assert r0["stats"]["schur_passes"] == 0 and r1["stats"]["schur_passes"] > 0
+    assert_same_outcome(r1, r0["info"], r0["x"], r0["y"], p, ITERATE_RTOL_PCG)
+    assert [t["n_active"] for t in r1["trace"]] == [t["n_active"] for t in r0["trace"]]
+    o = ob.OracleSolver(p, ob.default_settings())
+    ro = o.solve()
+    assert_same_outcome(r1, ro["info"], ro["x"], ro["y"], p, ITERATE_RTOL_PCG)
+    o.close()
+
+
 def test_config2_full_size_properties(gpu_required):
     """BASELINE.json configs[1]: n=1e4, m=2e4, 1 % fill.  The oracle's dense factor is out of reach at this
     size, so the check is through size-independent properties: termination status, independently recomputed
