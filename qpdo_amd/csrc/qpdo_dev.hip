@@ -134,7 +134,7 @@ struct QpdoDev {
     // Schur-complement mode of the PCG (pcg_solve): inner CG on S' = D^-1 + A_c Dq^-1 A_c' with its own control block
     Ctrl *ctrl2 = nullptr, *hctrl2 = nullptr; double *part2 = nullptr;
     double *s_x = nullptr, *s_r = nullptr, *s_z = nullptr, *s_p = nullptr, *s_Sp = nullptr, *s_diag = nullptr, *s_v = nullptr;
-    int schur_mode = -1 /* -1 auto, 0 off, 1 on */, schur_off = 0, schur_strikes = 0, last_jacobi_iters = 0; long long schur_passes = 0;
+    int schur_mode = -1 /* -1 auto, 0 off, 1 on */, schur_off = 0, schur_strikes = 0, last_jacobi_iters = 0, schur_last_inner = 0; long long schur_passes = 0;
     double *part = nullptr;  // P_COUNT * PGRID
     // scaling
     int scaled = 0; double sc_c = 1.0, sc_cinv = 1.0;
@@ -2889,26 +2889,34 @@ static int schur_inner_solve(QpdoDev *d, double tol, int *iters) {
     LAUNCH(k_pcg_init2, 1, (const double *)(P2 + 1 * PGRID), g, (const double *)(P2 + 2 * PGRID), g, d->ctrl2);
     const int pcnt = spmv_pgrid(d->Arc);
     int it = 0;
+    // Batches between host syncs.  The iteration count of an inner solve is almost the same as that of the previous one
+    // in the pass (same operator, same tolerance), so the first batch runs to just short of it and the rest are short:
+    // few syncs and few latched (no-op) launches after convergence.
+    int batch = d->schur_last_inner > 12 ? d->schur_last_inner - 6 : d->pcg_batch;
     while (it < SCHUR_INNER_MAXIT) {
-        const int it_before = it;
-        for (int b = 0; b < d->pcg_batch; b++) {
+        const int it_before = it, sample_b = batch / 2;
+        for (int b = 0; b < batch; b++) {
             launch_spmv_pcg(d, d->Atc, d->s_p, EpiDivStore{d->pc_diag, d->tmp_n}, false, done2);
-            if (b == 0) (void)hipEventRecord(d->ev0, d->stream);      // HIP-event sample of the dominant kernel, one per batch
+            // HIP-event sample of the dominant kernel, one per batch, taken mid-batch (the first launches after a host
+            // sync run on an idle GPU and would bias the sample)
+            if (b == sample_b) (void)hipEventRecord(d->ev0, d->stream);
             launch_spmv_pcg(d, d->Arc, d->tmp_n, EpiSchurA{d->dc, d->s_p, d->s_Sp, P2}, true, done2);
-            if (b == 0) (void)hipEventRecord(d->ev1, d->stream);
+            if (b == sample_b) (void)hipEventRecord(d->ev1, d->stream);
             LAUNCH(k_pcg_update, g, k, (const Ctrl *)d->ctrl2, (const double *)P2, pcnt, (const double *)d->s_p, (const double *)d->s_Sp,
                    (const double *)d->s_diag, d->s_x, d->s_r, d->s_z, P2 + 1 * PGRID, P2 + 2 * PGRID);
             LAUNCH(k_pcg_scalar, 1, d->ctrl2, (const double *)(P2 + 1 * PGRID), g, (const double *)(P2 + 2 * PGRID), g, tol);
             LAUNCH(k_pcg_p, g, k, (const Ctrl *)d->ctrl2, (const double *)d->s_z, d->s_p);
         }
-        it += d->pcg_batch;
+        it += batch;
         int rc = read_ctrl2(d); if (rc) return rc;
-        if (d->hctrl2->cnt[C_PCG_IT] > it_before) {          // the sampled (first) iteration of this batch really ran
+        if (d->hctrl2->cnt[C_PCG_IT] > it_before + sample_b) {          // the sampled iteration of this batch really ran
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, d->ev0, d->ev1) == hipSuccess) { d->ev_ac_ms += ms; d->ev_ac_bytes += d->Arc.alg_bytes(); d->ev_ac_n++; }
         }
         if (d->hctrl2->cnt[C_PCG_DONE]) break;
+        batch = 4;
     }
+    d->schur_last_inner = d->hctrl2->cnt[C_PCG_IT];
     *iters = d->hctrl2->cnt[C_PCG_IT];
     return d->hctrl2->cnt[C_PCG_DONE] ? 0 : 1;          // 1: not converged
 }
@@ -2938,6 +2946,7 @@ static int pcg_schur_solve(QpdoDev *d, int *iters_out, int *fallback) {
     LAUNCH(k_pcg_init, g, n, d->rhs, d->pc_diag, d->dx, d->pc_r, d->pc_z, d->pc_p, P + P_RZ * PGRID, P + P_RR * PGRID);
     { int rc0 = read_ctrl(d); if (rc0) return rc0; }
     const double dmax = nrm_of(d->hctrl, N_A);
+    d->schur_last_inner = 0;
     double tau = 1e-6 * (dmax > 1e4 ? 1e4 / dmax : 1.0);
     if (tau < 1e-13) tau = 1e-13;
     int inner = 0, st = 0;
