@@ -39,6 +39,7 @@ def parse():
                          "rows of A are partitioned over the GPUs with an RCCL all-reduce per A' product (strong scaling)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="bound of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mixed-extra", action="store_true", help="skip the informational fp32-inner-preconditioner solve")
     return ap.parse_args()
 
 
@@ -225,6 +226,24 @@ def main():
         except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU line
             out["cpu_baseline"] = dict(value=None, unit="newton_iters/s", cores=1, kind="port", sample="failed: %r" % (e,))
     s.delete()
+    if rank == 0 and world == 1 and schur_passes and not a.no_mixed_extra:
+        # Informational extra, NOT part of `value`: the same solve with the opt-in fp32 copy of the inner preconditioner's
+        # matrix values (QPDO_PCG_INNER_F32=1; every vector, accumulation and the outer CG on the exact K stay fp64).
+        try:
+            os.environ["QPDO_PCG_INNER_F32"] = "1"
+            s2 = solver.QPDO().setup(prob["Q"], prob["q"], prob["A"], prob["l"], prob["u"], Qstype=-1, **st)
+            t0 = time.time(); r2 = s2.solve(); L.qpdo_amd_sync(s2._w); dt2 = time.time() - t0
+            rp2, rd2 = problems.kkt_residuals(prob, r2["x"], r2["y"]) if r2["info"]["status_val"] == 1 else (None, None)
+            out["extra_fp32_inner_preconditioner"] = dict(time_to_eps_s=dt2, newton_iters_per_s=s2.stats()["newton_passes"] / dt2,
+                                                          status_val=r2["info"]["status_val"], iterations=r2["info"]["iterations"],
+                                                          oterations=r2["info"]["oterations"], kkt_prim=rp2, kkt_dual=rd2,
+                                                          max_abs_dx_vs_fp64_run=float(abs(r2["x"] - last["x"]).max()),
+                                                          note="opt-in; not the measured configuration")
+            s2.delete()
+        except Exception as e:
+            out["extra_fp32_inner_preconditioner"] = dict(error=repr(e))
+        finally:
+            os.environ.pop("QPDO_PCG_INNER_F32", None)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -18,6 +18,8 @@
  *   QPDO_DEFLATE     "0" disables the heavy-row deflation of the PCG preconditioner
  *   QPDO_IDX16       "0" disables the 16-bit slab-local column indices
  *   QPDO_PCG_SCHUR   "0" disables / "1" forces the Schur-complement mode of the PCG (default: automatic)
+ *   QPDO_PCG_INNER_F32  "1": the Schur mode's inner (preconditioner) solve streams an fp32 copy of the compact matrix values;
+ *                    vectors, accumulation and the outer CG on the exact K stay fp64 (opt-in, default off)
  *   QPDO_PCG_TOL     relative residual tolerance of the Jacobi-PCG solve (default 1e-12)
  *   QPDO_PCG_MAXIT   PCG iteration cap per Newton step (default 100000)
  *   QPDO_FIX_STATUS_RESET  "1": reset info->status_val at the start of qpdo_solve

@@ -73,6 +73,7 @@ struct DevCsr {
     // row stride (measured on C4: 6.4 -> 7.3 TB/s algorithmic).  seg[r*nslabs+s] = {start, length}; rebuilt lazily
     // (sm_dirty) after the values or the structure of the row-major arrays change.
     double *vsm = nullptr; unsigned short *i16sm = nullptr; int *cism = nullptr; int2 *seg = nullptr; mutable int sm_dirty = 1;
+    float *vsm32 = nullptr;           // optional fp32 copy of vsm (QPDO_PCG_INNER_F32: values of the Schur mode's inner preconditioner solve)
     double alg_bytes() const { return 12.0 * (double)nnz + 4.0 * (nrows + 1) + 8.0 * nrows + 8.0 * ncols; }
 };
 
@@ -134,7 +135,7 @@ struct QpdoDev {
     // Schur-complement mode of the PCG (pcg_solve): inner CG on S' = D^-1 + A_c Dq^-1 A_c' with its own control block
     Ctrl *ctrl2 = nullptr, *hctrl2 = nullptr; double *part2 = nullptr;
     double *s_x = nullptr, *s_r = nullptr, *s_z = nullptr, *s_p = nullptr, *s_Sp = nullptr, *s_diag = nullptr, *s_v = nullptr;
-    int schur_mode = -1 /* -1 auto, 0 off, 1 on */, schur_off = 0, schur_strikes = 0, last_jacobi_iters = 0, schur_last_inner = 0; long long schur_passes = 0;
+    int inner_f32 = 0; int schur_mode = -1 /* -1 auto, 0 off, 1 on */, schur_off = 0, schur_strikes = 0, last_jacobi_iters = 0, schur_last_inner = 0; long long schur_passes = 0;
     double *part = nullptr;  // P_COUNT * PGRID
     // scaling
     int scaled = 0; double sc_c = 1.0, sc_cinv = 1.0;
@@ -356,6 +357,86 @@ __global__ __launch_bounds__(1024) void k_spmv_slab(const int *__restrict__ done
     for (int r = tid; r < R; r += SLAB_THREADS) epi.row(row0 + r, acc[r]);
     epi.finish(sm);
 }
+// fp32-value variant for the inner solve of the Schur mode (opt-in, QPDO_PCG_INNER_F32=1): the inner system only defines
+// a preconditioner, so its matrix may be a rounded copy -- M32 = Dq + A32' D A32 is still SPD and differs from M by 1e-7
+// relative in the stiff subspace -- while every vector, every accumulation and the outer CG on the exact K stay fp64.
+// Streams 6 instead of 10 bytes per nonzero: 16-byte loads of 4 values + 8-byte loads of 4 indices, 4 in flight per lane.
+template <class Epi>
+__global__ __launch_bounds__(1024) void k_spmv_slab32(const int *__restrict__ done, int nrows, int ncols, int nslabs, int W,
+                                                      int rows_per_wg, const int2 *__restrict__ seg, const unsigned short *__restrict__ i16sm,
+                                                      const float *__restrict__ vsm32, const double *__restrict__ x, Epi epi) {
+    constexpr int TPR = 16;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double sm[32];
+    __shared__ int next_row;
+    if (done && *done) return;
+    double *xs = lds;
+    double *acc = lds + W;
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * rows_per_wg;
+    const int R = min(rows_per_wg, nrows - row0);
+    for (int r = tid; r < R; r += SLAB_THREADS) acc[r] = 0.0;
+    const int lane = tid & (TPR - 1);
+    for (int s = 0; s < nslabs; s++) {
+        const int c0 = s * W;
+        const int cw = min(W, ncols - c0);
+        __syncthreads();
+        {
+            const int pairs = cw >> 1;
+            const double2 *src = reinterpret_cast<const double2 *>(x + c0);
+            double2 *dst = reinterpret_cast<double2 *>(xs);
+            for (int i = tid; i < pairs; i += SLAB_THREADS) dst[i] = src[i];
+            if ((cw & 1) && tid == 0) xs[cw - 1] = x[c0 + cw - 1];
+            if (tid == 0) next_row = 0;
+        }
+        __syncthreads();
+        const int gw = (tid & 63) / TPR;
+        for (;;) {
+            int base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(&next_row, 64 / TPR);
+            base = __shfl(base, 0, 64);
+            if (base >= R) break;
+            const int r = base + gw;
+            if (r >= R) continue;
+            const int row = row0 + r;
+            const int2 sg = seg[(size_t)row * nslabs + s];
+            const int beg = sg.x, end = sg.x + sg.y;
+            const int kb = beg & ~3;
+            double sa[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) sa[u] = 0.0;
+            for (int k = kb + 4 * lane; k < end; k += 16 * TPR) {
+                float4 v[4]; ushort4 a[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int kk = k + u * 4 * TPR;
+                    const int kc = kk < end ? kk : kb;
+                    v[u] = *reinterpret_cast<const float4 *>(vsm32 + kc);
+                    a[u] = *reinterpret_cast<const ushort4 *>(i16sm + kc);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int kk = k + u * 4 * TPR;
+                    const double p0 = (double)v[u].x * xs[a[u].x], p1 = (double)v[u].y * xs[a[u].y];
+                    const double p2 = (double)v[u].z * xs[a[u].z], p3 = (double)v[u].w * xs[a[u].w];
+                    sa[4 * u]     += (kk >= beg && kk < end) ? p0 : 0.0;
+                    sa[4 * u + 1] += (kk + 1 >= beg && kk + 1 < end) ? p1 : 0.0;
+                    sa[4 * u + 2] += (kk + 2 >= beg && kk + 2 < end) ? p2 : 0.0;
+                    sa[4 * u + 3] += (kk + 3 < end) ? p3 : 0.0;
+                }
+            }
+            double t = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) t += sa[2 * u] + sa[2 * u + 1];
+#pragma unroll
+            for (int o = TPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, TPR);
+            if (lane == 0) acc[r] += t;
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < R; r += SLAB_THREADS) epi.row(row0 + r, acc[r]);
+    epi.finish(sm);
+}
 // slab pointers by binary search in each (column-sorted) row; also flags unsorted rows
 __global__ void k_build_slab_ptr(int nrows, const int *__restrict__ rp, const int *__restrict__ ci, int nslabs, int W,
                                  int *__restrict__ sp, int *__restrict__ unsorted) {
@@ -401,7 +482,7 @@ __global__ __launch_bounds__(1024) void k_slab_seg(int nrows, int nslabs, int ro
 __global__ __launch_bounds__(256) void k_slab_permute(int nrows, int nslabs, int W, const int *__restrict__ sp, const int2 *__restrict__ seg,
                                                       const int *__restrict__ ci, const unsigned short *__restrict__ ci16,
                                                       const double *__restrict__ val, double *__restrict__ vsm,
-                                                      unsigned short *__restrict__ i16sm, int *__restrict__ cism) {
+                                                      unsigned short *__restrict__ i16sm, int *__restrict__ cism, float *__restrict__ vsm32) {
     const int lane = threadIdx.x & 15;
     const int ngroups = gridDim.x * (blockDim.x >> 4);
     for (int row = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); row < nrows; row += ngroups)
@@ -409,7 +490,9 @@ __global__ __launch_bounds__(256) void k_slab_permute(int nrows, int nslabs, int
             const int src = sp[(size_t)row * (nslabs + 1) + sl];
             const int2 sg = seg[(size_t)row * nslabs + sl];
             for (int e = lane; e < sg.y; e += 16) {
-                vsm[sg.x + e] = val[src + e];
+                const double v = val[src + e];
+                vsm[sg.x + e] = v;
+                if (vsm32) vsm32[sg.x + e] = (float)v;
                 if (i16sm) i16sm[sg.x + e] = ci16[src + e]; else cism[sg.x + e] = ci[src + e] - sl * W;
             }
         }
@@ -572,6 +655,17 @@ static void launch_spmv_slab(QpdoDev *d, const DevCsr &M, const double *x, Epi e
     if (M.i16sm) { if (g_slab_tpr == 8) SLAB_GO(true, 8); else if (g_slab_tpr == 32) SLAB_GO(true, 32); else SLAB_GO(true, 16); }
     else        { if (g_slab_tpr == 8) SLAB_GO(false, 8); else if (g_slab_tpr == 32) SLAB_GO(false, 32); else SLAB_GO(false, 16); }
 #undef SLAB_GO
+    d->st.spmv_calls++;
+    d->st.spmv_bytes += (int64_t)M.alg_bytes();
+}
+template <class Epi>
+static void launch_spmv_slab32(QpdoDev *d, const DevCsr &M, const double *x, Epi epi, const int *done) {
+    const size_t lds = ((size_t)M.W + (size_t)M.rows_per_wg) * sizeof(double);
+    static thread_local bool attr_set = false;   // per instantiation
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab32<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr_set = true; }
+    if (M.sm_dirty) slab_major_build(d, M);
+    hipLaunchKernelGGL((k_spmv_slab32<Epi>), dim3(M.slab_grid), dim3(SLAB_THREADS), lds, d->stream, done, M.nrows, M.ncols, M.nslabs, M.W, M.rows_per_wg,
+                       (const int2 *)M.seg, (const unsigned short *)M.i16sm, (const float *)M.vsm32, x, epi);
     d->st.spmv_calls++;
     d->st.spmv_bytes += (int64_t)M.alg_bytes();
 }
@@ -2210,13 +2304,16 @@ static int upload_csr(QpdoDev *d, DevCsr *M, const QdevCsr *h) {
 static int read_ctrl(QpdoDev *d);
 // decide whether M streams from HBM (then use the LDS-staged kernel) and build its slab pointers
 // arrays of the slab-major image (two padding entries: the 16-byte loads may touch one element past a segment)
-static int slab_major_alloc(QpdoDev *d, DevCsr *M, size_t nnz_cap, size_t nseg) {
-    int rc = dev_alloc(d, &M->vsm, nnz_cap + 2);
-    if (!rc) rc = M->ci16 ? dev_alloc(d, &M->i16sm, nnz_cap + 2) : dev_alloc(d, &M->cism, nnz_cap + 2);
+static int slab_major_alloc(QpdoDev *d, DevCsr *M, size_t nnz_cap, size_t nseg, bool with_f32 = false) {
+    const size_t PAD = 4;       // the vector loads may touch up to three elements past a segment
+    int rc = dev_alloc(d, &M->vsm, nnz_cap + PAD);
+    if (!rc) rc = M->ci16 ? dev_alloc(d, &M->i16sm, nnz_cap + PAD) : dev_alloc(d, &M->cism, nnz_cap + PAD);
+    if (!rc && with_f32 && M->ci16) rc = dev_alloc(d, &M->vsm32, nnz_cap + PAD);
     if (!rc) rc = dev_alloc(d, &M->seg, nseg > 0 ? nseg : 1);
     if (!rc) {
-        hipError_t e = hipMemsetAsync(M->vsm + nnz_cap, 0, 2 * sizeof(double), d->stream);
-        if (e == hipSuccess) e = M->i16sm ? hipMemsetAsync(M->i16sm + nnz_cap, 0, 2 * sizeof(unsigned short), d->stream) : hipMemsetAsync(M->cism + nnz_cap, 0, 2 * sizeof(int), d->stream);
+        hipError_t e = hipMemsetAsync(M->vsm + nnz_cap, 0, PAD * sizeof(double), d->stream);
+        if (e == hipSuccess) e = M->i16sm ? hipMemsetAsync(M->i16sm + nnz_cap, 0, PAD * sizeof(unsigned short), d->stream) : hipMemsetAsync(M->cism + nnz_cap, 0, PAD * sizeof(int), d->stream);
+        if (e == hipSuccess && M->vsm32) e = hipMemsetAsync(M->vsm32 + nnz_cap, 0, PAD * sizeof(float), d->stream);
         if (e != hipSuccess) rc = set_err(e, "hipMemsetAsync", __LINE__);
     }
     M->sm_dirty = 1;
@@ -2261,7 +2358,7 @@ static int setup_slabs(QpdoDev *d, DevCsr *M) {
 static void slab_major_build(QpdoDev *d, const DevCsr &M) {
     hipLaunchKernelGGL(k_slab_seg, dim3(M.slab_grid), dim3(1024), 0, d->stream, M.nrows, M.nslabs, M.rows_per_wg, (const int *)M.sp, M.seg);
     hipLaunchKernelGGL(k_slab_permute, dim3(2048), dim3(256), 0, d->stream, M.nrows, M.nslabs, M.W, (const int *)M.sp, (const int2 *)M.seg,
-                       (const int *)M.ci, (const unsigned short *)M.ci16, (const double *)M.val, M.vsm, M.i16sm, M.cism);
+                       (const int *)M.ci, (const unsigned short *)M.ci16, (const double *)M.val, M.vsm, M.i16sm, M.cism, M.vsm32);
     M.sm_dirty = 0;
 }
 static int read_ctrl(QpdoDev *d) {
@@ -2425,20 +2522,21 @@ int qdev_create_dist(QpdoDev **out, int device, int32_t n, int32_t m, const Qdev
     if (!rc) {   // per-pass compact copies used by PCG
         d->Arc = d->Ar; d->Arc.rp = nullptr; d->Arc.ci = nullptr; d->Arc.val = nullptr; d->Arc.sp = nullptr; d->Arc.ci16 = nullptr;
         d->Atc = d->At; d->Atc.rp = nullptr; d->Atc.ci = nullptr; d->Atc.val = nullptr; d->Atc.sp = nullptr; d->Atc.ci16 = nullptr;
-        d->Arc.vsm = nullptr; d->Arc.i16sm = nullptr; d->Arc.cism = nullptr; d->Arc.seg = nullptr;
-        d->Atc.vsm = nullptr; d->Atc.i16sm = nullptr; d->Atc.cism = nullptr; d->Atc.seg = nullptr;
+        d->Arc.vsm = nullptr; d->Arc.i16sm = nullptr; d->Arc.cism = nullptr; d->Arc.seg = nullptr; d->Arc.vsm32 = nullptr;
+        d->Atc.vsm = nullptr; d->Atc.i16sm = nullptr; d->Atc.cism = nullptr; d->Atc.seg = nullptr; d->Atc.vsm32 = nullptr;
+        { const char *f32 = getenv("QPDO_PCG_INNER_F32"); d->inner_f32 = (f32 && atoi(f32) != 0) ? 1 : 0; }
         rc = dev_alloc(d, &d->Arc.rp, (size_t)m + 1);
         if (!rc) rc = dev_alloc(d, &d->Arc.ci, (size_t)Ar->nnz);
         if (!rc) rc = dev_alloc(d, &d->Arc.val, (size_t)Ar->nnz);
         if (!rc && d->Ar.use_slab) rc = dev_alloc(d, &d->Arc.sp, (size_t)m * (d->Ar.nslabs + 1));
         if (!rc && d->Ar.ci16) rc = dev_alloc(d, &d->Arc.ci16, (size_t)Ar->nnz);
-        if (!rc && d->Ar.use_slab) rc = slab_major_alloc(d, &d->Arc, (size_t)Ar->nnz, (size_t)m * d->Ar.nslabs);
+        if (!rc && d->Ar.use_slab) rc = slab_major_alloc(d, &d->Arc, (size_t)Ar->nnz, (size_t)m * d->Ar.nslabs, d->inner_f32 != 0);
         if (!rc) rc = dev_alloc(d, &d->Atc.rp, (size_t)n + 1);
         if (!rc) rc = dev_alloc(d, &d->Atc.ci, (size_t)At->nnz);
         if (!rc) rc = dev_alloc(d, &d->Atc.val, (size_t)At->nnz);
         if (!rc && d->At.use_slab) rc = dev_alloc(d, &d->Atc.sp, (size_t)n * (d->At.nslabs + 1));
         if (!rc && d->At.ci16) rc = dev_alloc(d, &d->Atc.ci16, (size_t)At->nnz);
-        if (!rc && d->At.use_slab) rc = slab_major_alloc(d, &d->Atc, (size_t)At->nnz, (size_t)n * d->At.nslabs);
+        if (!rc && d->At.use_slab) rc = slab_major_alloc(d, &d->Atc, (size_t)At->nnz, (size_t)n * d->At.nslabs, d->inner_f32 != 0);
         if (!rc) rc = dev_alloc(d, &d->row_cnt, (size_t)(n > m ? n : m));
         if (!rc) rc = dev_alloc(d, &d->cidx, (size_t)m);
         if (!rc) rc = dev_alloc(d, &d->rowlist, (size_t)m);
@@ -2896,11 +2994,14 @@ static int schur_inner_solve(QpdoDev *d, double tol, int *iters) {
     while (it < SCHUR_INNER_MAXIT) {
         const int it_before = it, sample_b = batch / 2;
         for (int b = 0; b < batch; b++) {
-            launch_spmv_pcg(d, d->Atc, d->s_p, EpiDivStore{d->pc_diag, d->tmp_n}, false, done2);
+            const bool f32 = d->inner_f32 && d->Atc.use_slab && d->Arc.use_slab && d->Atc.vsm32 && d->Arc.vsm32 && d->Atc.i16sm && d->Arc.i16sm;
+            if (f32) launch_spmv_slab32(d, d->Atc, d->s_p, EpiDivStore{d->pc_diag, d->tmp_n}, done2);
+            else launch_spmv_pcg(d, d->Atc, d->s_p, EpiDivStore{d->pc_diag, d->tmp_n}, false, done2);
             // HIP-event sample of the dominant kernel, one per batch, taken mid-batch (the first launches after a host
             // sync run on an idle GPU and would bias the sample)
             if (b == sample_b) (void)hipEventRecord(d->ev0, d->stream);
-            launch_spmv_pcg(d, d->Arc, d->tmp_n, EpiSchurA{d->dc, d->s_p, d->s_Sp, P2}, true, done2);
+            if (f32) launch_spmv_slab32(d, d->Arc, d->tmp_n, EpiSchurA{d->dc, d->s_p, d->s_Sp, P2}, done2);
+            else launch_spmv_pcg(d, d->Arc, d->tmp_n, EpiSchurA{d->dc, d->s_p, d->s_Sp, P2}, true, done2);
             if (b == sample_b) (void)hipEventRecord(d->ev1, d->stream);
             LAUNCH(k_pcg_update, g, k, (const Ctrl *)d->ctrl2, (const double *)P2, pcnt, (const double *)d->s_p, (const double *)d->s_Sp,
                    (const double *)d->s_diag, d->s_x, d->s_r, d->s_z, P2 + 1 * PGRID, P2 + 2 * PGRID);
