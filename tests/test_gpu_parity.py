@@ -250,6 +250,26 @@ def test_pcg_schur_mode_matches_jacobi_and_oracle(gpu_required, monkeypatch):
     o.close()
 
 
+def test_pcg_schur_fp32_inner_preconditioner_is_only_a_preconditioner(gpu_required, monkeypatch):
+    """opt-in QPDO_PCG_INNER_F32: the inner solve of the Schur mode streams an fp32 copy of the compact matrix values
+    (slab kernels forced so that the fp32 path is taken at this size); the outer CG runs on the exact fp64 operator
+    to the same tolerance, so counts and iterates must not move beyond the PCG tolerance"""
+    monkeypatch.setenv("QPDO_LINSOLVE", "pcg")
+    monkeypatch.setenv("QPDO_SPMV", "slab")
+    monkeypatch.setenv("QPDO_PCG_SCHUR", "1")
+    p = problems.random_qp(62, 800, 1500, 0.03, 0)
+    monkeypatch.setenv("QPDO_PCG_INNER_F32", "0")
+    r0 = solver.solve_problem(p, verbose=0)
+    monkeypatch.setenv("QPDO_PCG_INNER_F32", "1")
+    r1 = solver.solve_problem(p, verbose=0)
+    assert r0["stats"]["schur_passes"] > 0 and r1["stats"]["schur_passes"] > 0
+    assert_same_outcome(r1, r0["info"], r0["x"], r0["y"], p, ITERATE_RTOL_PCG)
+    o = ob.OracleSolver(p, ob.default_settings())
+    ro = o.solve()
+    assert_same_outcome(r1, ro["info"], ro["x"], ro["y"], p, ITERATE_RTOL_PCG)
+    o.close()
+
+
 def test_config2_full_size_properties(gpu_required):
     """BASELINE.json configs[1]: n=1e4, m=2e4, 1 % fill.  The oracle's dense factor is out of reach at this
     size, so the check is through size-independent properties: termination status, independently recomputed
