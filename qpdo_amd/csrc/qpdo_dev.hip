@@ -3083,6 +3083,9 @@ static int pcg_schur_solve(QpdoDev *d, int *iters_out, int *fallback) {
     if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[schur] dmax=%.2e tau_end=%.1e ", dmax, tau);
     *iters_out = outer + inner;
     d->schur_passes++;
+    // converged, but slowly: Q is far from its diagonal in the spectral sense and every outer step pays a full inner solve --
+    // the deflated Jacobi-PCG is the better solver for such a Q (two slow passes switch the mode off for the solve)
+    if (outer > 20 && ++d->schur_strikes >= 2) d->schur_off = 1;
     if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[schur] k=%d outer=%d inner=%d\n", k, outer, inner);
     return 0;
 }
