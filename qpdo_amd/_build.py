@@ -15,7 +15,8 @@ GEN_PATH = os.path.join(_HERE, "libqpdo_gen.so")
 
 HIP_SOURCES = ["qpdo_dev.hip", "qpdo_small.hip"]
 C_SOURCES = ["qpdo_api.c"]
-HEADERS = ["qpdo_dev.h", os.path.join(INCLUDE, "qpdo.h"), os.path.join(INCLUDE, "qpdo_amd_ext.h")]
+HEADERS = ["qpdo_dev.h", os.path.join(INCLUDE, "qpdo.h"), os.path.join(INCLUDE, "qpdo_amd_ext.h")] + \
+    sorted(os.path.join("dev", f) for f in os.listdir(os.path.join(CSRC, "dev")) if f.endswith(".inc"))
 
 
 def _stale(target, sources):

@@ -42,3637 +42,18 @@ static int set_err(hipError_t e, const char *what, int line) {
         if (e__ != hipSuccess) return set_err(e__, #call, __LINE__); \
     } while (0)
 
-// ------------------------------------------------------------------------------------------------
-// control block: everything the host reads back per pass
-// ------------------------------------------------------------------------------------------------
-enum { N_PRIM = 0, N_DUAL, N_PRIM_IN, N_DUAL_IN, N_A, N_B, N_C, N_D, N_COUNT };
-enum { C_ACTIVE = 0, C_ENTER, C_LEAVE, C_NL, C_KSTAR, C_MUCH, C_VIOL, C_PCG_DONE, C_PCG_IT, C_CHAIN_ERR, C_COUNT = 12 };
-enum { V_TAU = 0, V_A0, V_B0, V_RZ, V_BNORM, V_OOB, V_QDX, V_OBJ, V_F, V_RR, V_RNORM, V_COUNT = 16 };
-struct Ctrl {
-    u64 nrm[N_COUNT];      // non-negative doubles as bit patterns: atomicMax is exact and order free
-    int cnt[C_COUNT];
-    double val[V_COUNT];
-};
-
-// partial-sum slots (each PGRID doubles)
-enum { P_ETA_M = 0, P_BETA_M, P_A0, P_B0, P_DXQDX, P_DXDF, P_PKP, P_RZ, P_RR, P_OOB, P_QDX, P_OBJ, P_F1, P_F2, P_COUNT };
-
-struct DevCsr {
-    int nrows = 0, ncols = 0;
-    long long nnz = 0;
-    int *rp = nullptr, *ci = nullptr;
-    double *val = nullptr;
-    int tpr = 64;            // threads cooperating on one row
-    // LDS-staged variant: columns are cut into `nslabs` slabs of W columns; sp[r*(nslabs+1)+s] is the
-    // position inside row r where slab s starts (rows are column-sorted, so a slab is a sub-range)
-    int use_slab = 0, nslabs = 0, W = 0, rows_per_wg = 0, slab_grid = 0;
-    int *sp = nullptr;
-    unsigned short *ci16 = nullptr;   // column index inside its slab (W < 65536): 10 instead of 12 bytes per nonzero
-    // Slab-major image, the arrays the slab kernel actually streams: per workgroup the row segments of slab 0 back to
-    // back, then those of slab 1, ... so that a slab phase reads one sequential range instead of 1.3 KB pieces at a
-    // row stride (measured on C4: 6.4 -> 7.3 TB/s algorithmic).  seg[r*nslabs+s] = {start, length}; rebuilt lazily
-    // (sm_dirty) after the values or the structure of the row-major arrays change.
-    double *vsm = nullptr; unsigned short *i16sm = nullptr; int *cism = nullptr; int2 *seg = nullptr; mutable int sm_dirty = 1;
-    float *vsm32 = nullptr;           // optional fp32 copy of vsm (QPDO_PCG_INNER_F32: values of the Schur mode's inner preconditioner solve)
-    double alg_bytes() const { return 12.0 * (double)nnz + 4.0 * (nrows + 1) + 8.0 * nrows + 8.0 * ncols; }
-};
-
-// Row partition of one large QP over G ranks (one process per GPU): every vector is replicated, only the
-// matrices are split (rows [m0, m0+mloc) of A, the matching columns of A', rows [n0, n0+nloc) of Q for the PCG
-// operator).  The single exchange step is a sum all-reduce of an n-vector per A' / K product (plus max / sum
-// all-reduces of the Ruiz norms and of A x results): RCCL on the backend stream, or a host callback (tests).
-struct Comm {
-    int rank = 0, world = 1, mode = 0;          // mode: 0 none, 1 host callback, 2 RCCL
-    qdev_allreduce_fn fn = nullptr; void *ctx = nullptr;
-    ncclComm_t nccl = nullptr;
-    double *hbuf = nullptr; size_t hcap = 0;     // pinned staging for the host-callback mode
-};
-struct QpdoDev {
-    int device = 0, n = 0, m = 0;
-    int m0 = 0, mloc = 0, n0 = 0, nloc = 0;      // this rank's slices (whole ranges when world == 1)
-    Comm comm;
-    double *dist_tmp = nullptr, *Kp_part = nullptr, *zeros_n = nullptr;
-    hipStream_t stream = nullptr;
-    DevCsr Ar, At, Qf;        // world > 1: Ar = local rows (mloc x n), At = local columns (n x mloc), Qf replicated
-    DevCsr Qs;                // world > 1: rows [n0, n0+nloc) of Qf for the PCG operator
-    // compact index space of the current Newton pass: the k weighted rows of A, renumbered 0..k-1
-    DevCsr Arc, Atc;          // A_c (k x n) and A_c' (n x k)
-    int *row_cnt = nullptr, *cidx = nullptr, *rowlist = nullptr, *kcount = nullptr; int kact = 0;
-    double *dc = nullptr, *tc = nullptr; int lds_doubles_At = 0;
-    double *qdiag = nullptr; int qdiag_valid = 0;
-    // heavy-row deflation
-    int deflate = 1, defl_r = 0, max_row_nnz_A = 0; DevCsr Ath; int *defl_hist = nullptr, *defl_list = nullptr, *defl_count = nullptr;
-    double *defl_flag = nullptr, *defl_t = nullptr, *defl_S = nullptr, *defl_Sinv = nullptr, *defl_v = nullptr; long long defl_passes = 0;
-    // dense direct solver
-    int dense_ld = 0, dense_nblk = 0, dense_valid = 0;
-    int dense_max_n = 12288;  // dense beats deflated PCG at n = 1e4 (0.90 s vs 1.35 s at C2)
-    double *Kd = nullptr, *Wd = nullptr, *Dg = nullptr, *Linv = nullptr, *LinvT = nullptr, *dz = nullptr, *dxw = nullptr;
-    double *ch_y = nullptr, *ch_x = nullptr, *dsol = nullptr; int dense_chain = 1;
-    hipStream_t stream2 = nullptr;            // dense factor look-ahead: trailing updates run here
-    // low-rank factor update (Woodbury on the kept factor): see the k_wb_* kernels
-    int dense_factored = 0, wb_enable = 1, wb_k = 0; double dense_fact_sigma = 0.0;
-    double *d_fact = nullptr, *wb_Z = nullptr, *wb_T = nullptr, *wb_G = nullptr, *wb_v = nullptr, *wb_w = nullptr, *wb_t = nullptr;
-    int *wb_slot = nullptr, *wb_rows = nullptr, *wb_cnt = nullptr;
-    hipEvent_t evF[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr};
-    int dense_last_branch = -1; double dense_last_sigma = -1.0;
-    // n-vectors
-    double *x, *xbar, *Qx, *Aty, *q, *df, *res_dual, *res_dual_in, *rhs, *dx, *Qdx, *Atdy, *D, *Dinv;
-    double *pc_r, *pc_z, *pc_p, *pc_Kp, *pc_diag, *tmp_n;
-    // m-vectors
-    double *y, *ybar, *Ax, *l, *u, *mu, *isq, *w, *res_prim, *res_prim_old, *res_prim_in, *dy, *Adx, *d, *E,
-        *Einv, *pc_t, *at_scale, *tmp_m;
-    int *active, *active_old, *mu_changed;
-    // 2m linesearch
-    double *ls_delta, *ls_alpha, *ls_pa, *ls_pb;
-    u64 *ls_key[2];
-    u32 *ls_idx[2];
-    int *rs_hist; int rs_nblocks = 0;
-    double *ls_bt;           // block totals (2 * nblk)
-    int ls_nblk = 0;
-    // control
-    Ctrl *ctrl = nullptr;    // device
-    Ctrl *hctrl = nullptr;   // pinned host
-    // Schur-complement mode of the PCG (pcg_solve): inner CG on S' = D^-1 + A_c Dq^-1 A_c' with its own control block
-    Ctrl *ctrl2 = nullptr, *hctrl2 = nullptr; double *part2 = nullptr;
-    double *s_x = nullptr, *s_r = nullptr, *s_z = nullptr, *s_p = nullptr, *s_Sp = nullptr, *s_diag = nullptr, *s_v = nullptr;
-    int inner_f32 = 0; int schur_mode = -1 /* -1 auto, 0 off, 1 on */, schur_off = 0, schur_strikes = 0, last_jacobi_iters = 0, schur_last_inner = 0; long long schur_passes = 0;
-    double *part = nullptr;  // P_COUNT * PGRID
-    // scaling
-    int scaled = 0; double sc_c = 1.0, sc_cinv = 1.0;
-    // factor state
-    double sigma_f = 0.0;
-    // config
-    int linsolve = 0; double pcg_tol = 1e-12; int pcg_maxit = 100000; int pcg_batch = 16; int pcg_graph = 1;
-    // stats
-    QdevStats st{};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double ev_spmv_ms = 0.0; long long ev_spmv_n = 0;
-    double ev_ac_ms = 0.0, ev_ac_bytes = 0.0; long long ev_ac_n = 0;      // sampled A_c products of the Schur mode's inner solve
-    std::vector<void *> allocs;
-};
-
-// ------------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-// sum over the block; result valid in every thread.  sm: >= 4 doubles of LDS.
-__device__ __forceinline__ double block_sum(double v, double *sm) {
-    v = wave_sum(v);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    __syncthreads();
-    if (l == 0) sm[w] = v;
-    __syncthreads();
-    double t = sm[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); i++) t += sm[i];
-    return t;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_down(v, o, 64); v = t > v ? t : v; }
-    return v;
-}
-// max over block of non-negative values then one atomicMax on the bit pattern (exact).
-__device__ __forceinline__ void block_max_to(double v, u64 *dst, double *sm) {
-    v = wave_max(v);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    __syncthreads();
-    if (l == 0) sm[w] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = sm[0];
-        for (int i = 1; i < (int)(blockDim.x >> 6); i++) t = sm[i] > t ? sm[i] : t;
-        if (t > 0.0) atomicMax(dst, (u64)__double_as_longlong(t));
-    }
-}
-// reference c_absval / '>' semantics: a NaN never replaces the running maximum (lin_alg.c:107-140)
-__device__ __forceinline__ double absmax_acc(double mx, double a) {
-    double s = a < 0 ? -a : a;
-    return s > mx ? s : mx;
-}
-__device__ __forceinline__ double mid3(double a, double lo, double hi) {   // lin_alg.c:163-168
-    double t = a < hi ? a : hi;
-    return lo > t ? lo : t;
-}
-// every block re-reduces `cnt` per-block partial sums in a fixed order (deterministic)
-__device__ __forceinline__ double reduce_partials(const double *p, int cnt, double *sm) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) s += p[i];
-    return block_sum(s, sm);
-}
-__device__ __forceinline__ int block_sum_int(int v, int *sm) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    __syncthreads();
-    if (l == 0) sm[w] = v;
-    __syncthreads();
-    int t = 0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += sm[i];
-    return t;
-}
-
-static inline int vgrid(long long len) {
-    long long g = (len + BLK - 1) / BLK;
-    if (g < 1) g = 1;
-    if (g > PGRID) g = PGRID;
-    return (int)g;
-}
-
-// ------------------------------------------------------------------------------------------------
-// SpMV: y = M x, CSR, TPR lanes cooperate on a row, shuffle reduction inside the lane group.
-// The epilogue functor receives the row sum in lane 0 of the group and may fuse the vector work
-// that follows the product in the reference (S1/S2 + V1, N5, L1 of SURVEY section 8).
-// ------------------------------------------------------------------------------------------------
-template <int TPR>
-__device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int o = TPR / 2; o > 0; o >>= 1) v += __shfl_down(v, o, TPR);
-    return v;
-}
-
-template <int TPR, class Epi>
-__global__ __launch_bounds__(256) void k_spmv(int nrows, const int *__restrict__ rp, const int *__restrict__ ci,
-                                              const double *__restrict__ val, const double *__restrict__ x, Epi epi) {
-    __shared__ double sm[32];
-    const int lane = threadIdx.x % TPR;
-    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
-    const int ngroups = gridDim.x * (BLK / TPR);
-    for (int row = group; row < nrows; row += ngroups) {
-        double s = 0.0;
-        if (!epi.skip(row)) {
-            const int beg = rp[row], end = rp[row + 1];
-            double s0 = 0.0, s1 = 0.0;
-            int k = beg + lane;
-            for (; k + TPR < end; k += 2 * TPR) {
-                const double v0 = val[k], v1 = val[k + TPR];
-                const int c0 = ci[k], c1 = ci[k + TPR];
-                s0 += v0 * x[c0];
-                s1 += v1 * x[c1];
-            }
-            if (k < end) s0 += val[k] * x[ci[k]];
-            s = group_sum<TPR>(s0 + s1);
-        }
-        if (lane == 0) epi.row(row, s);
-    }
-    epi.finish(sm);
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// LDS-staged SpMV for matrices that stream from HBM (BASELINE north star: "coalesced CSR row loads
-// staged in LDS with wavefront __shfl reductions").  One 1024-thread workgroup per CU owns a block of
-// consecutive rows and walks the column slabs; for each slab the x-slice (W doubles, up to ~150 KB)
-// is copied once into LDS with coalesced loads, then 16-lane groups stream their rows' sub-ranges
-// (contiguous val / col-index runs) and gather x from LDS instead of from L2.  Row sums accumulate
-// in LDS across slabs in a fixed order, so results are reproducible.
-// ------------------------------------------------------------------------------------------------
-static const int SLAB_THREADS = 1024;
-#define SLAB_UNR 8               // 16-byte loads in flight per lane
-static int g_slab_tpr = 16;     // lanes per row segment (QPDO_SLAB_TPR: 8 | 16 | 32; 16 x 16-byte loads measured best at C4)
-template <class Epi, bool I16, int TPR>
-__global__ __launch_bounds__(1024) void k_spmv_slab(const int *__restrict__ done, int nrows, int ncols, int nslabs, int W,
-                                                    int rows_per_wg, const int2 *__restrict__ seg, const int *__restrict__ cism,
-                                                    const unsigned short *__restrict__ i16sm,
-                                                    const double *__restrict__ vsm, const double *__restrict__ x, Epi epi) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ double sm[32];
-    __shared__ int next_row;
-    if (done && *done) return;
-    double *xs = lds;
-    double *acc = lds + W;
-    const int tid = threadIdx.x;
-    const int row0 = blockIdx.x * rows_per_wg;
-    const int R = min(rows_per_wg, nrows - row0);
-    for (int r = tid; r < R; r += SLAB_THREADS) acc[r] = 0.0;
-    const int lane = tid & (TPR - 1);
-    for (int s = 0; s < nslabs; s++) {
-        const int c0 = s * W;
-        const int cw = min(W, ncols - c0);
-        __syncthreads();
-        {   // stage x[c0 .. c0+cw) : 16-byte loads, then the odd tail
-            const int pairs = cw >> 1;
-            const double2 *src = reinterpret_cast<const double2 *>(x + c0);
-            double2 *dst = reinterpret_cast<double2 *>(xs);
-            for (int i = tid; i < pairs; i += SLAB_THREADS) dst[i] = src[i];
-            if ((cw & 1) && tid == 0) xs[cw - 1] = x[c0 + cw - 1];
-            if (tid == 0) next_row = 0;
-        }
-        __syncthreads();
-        // Rows are handed out dynamically (LDS counter): with only a few row segments per lane group and slab a
-        // static split leaves groups idle at the end-of-slab barrier.  One lane per WAVE grabs a batch of 64/TPR
-        // rows and broadcasts it wave-wide, so the loop exit is wave-uniform (no divergent break around the
-        // shuffles).  Which group takes a row does not change the row's arithmetic: results stay reproducible.
-        const int gw = (tid & 63) / TPR;                 // group index inside the wave
-        for (;;) {
-            int base = 0;
-            if ((tid & 63) == 0) base = atomicAdd(&next_row, 64 / TPR);
-            base = __shfl(base, 0, 64);
-            if (base >= R) break;
-            const int r = base + gw;
-            if (r >= R) continue;
-            const int row = row0 + r;
-            if (epi.skip(row)) continue;
-            const int2 sg = seg[(size_t)row * nslabs + s];
-            const int beg = sg.x, end = sg.x + sg.y;
-            // 16-byte value loads and paired index loads from an even start (the element before an odd `beg` and the
-            // one after an odd end are masked): one instruction covers 2*TPR consecutive entries and SLAB_UNR of them
-            // are in flight per lane -- a C4 segment (~170 entries) is a single trip.  No scalar tail loop: slots past
-            // the end re-read the first pair and contribute exact zeros.  (Lab, tools/lab/slab_lab.hip, C4 shape:
-            // 8-byte loads x4: 5.8 TB/s; 16-byte x4: 6.2; x8: 6.9 with the slab-major image, 6.2 without.)
-            const int kb = beg & ~1;
-            double sa[2 * SLAB_UNR];
-#pragma unroll
-            for (int u = 0; u < 2 * SLAB_UNR; u++) sa[u] = 0.0;
-            for (int k = kb + 2 * lane; k < end; k += 2 * SLAB_UNR * TPR) {
-                double2 v[SLAB_UNR]; int ax[SLAB_UNR], ay[SLAB_UNR];
-#pragma unroll
-                for (int u = 0; u < SLAB_UNR; u++) {
-                    const int kk = k + u * 2 * TPR;
-                    const int kc = kk < end ? kk : kb;
-                    v[u] = *reinterpret_cast<const double2 *>(vsm + kc);
-                    if (I16) { const ushort2 a = *reinterpret_cast<const ushort2 *>(i16sm + kc); ax[u] = a.x; ay[u] = a.y; }
-                    else     { const int2 a = *reinterpret_cast<const int2 *>(cism + kc); ax[u] = a.x; ay[u] = a.y; }
-                }
-#pragma unroll
-                for (int u = 0; u < SLAB_UNR; u++) {
-                    const int kk = k + u * 2 * TPR;
-                    const double px = v[u].x * xs[ax[u]], py = v[u].y * xs[ay[u]];
-                    sa[2 * u] += (kk >= beg && kk < end) ? px : 0.0;
-                    sa[2 * u + 1] += (kk + 1 < end) ? py : 0.0;
-                }
-            }
-            double t = 0.0;
-#pragma unroll
-            for (int u = 0; u < SLAB_UNR; u++) t += sa[2 * u] + sa[2 * u + 1];
-#pragma unroll
-            for (int o = TPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, TPR);
-            if (lane == 0) acc[r] += t;
-        }
-    }
-    __syncthreads();
-    for (int r = tid; r < R; r += SLAB_THREADS) epi.row(row0 + r, acc[r]);
-    epi.finish(sm);
-}
-// fp32-value variant for the inner solve of the Schur mode (opt-in, QPDO_PCG_INNER_F32=1): the inner system only defines
-// a preconditioner, so its matrix may be a rounded copy -- M32 = Dq + A32' D A32 is still SPD and differs from M by 1e-7
-// relative in the stiff subspace -- while every vector, every accumulation and the outer CG on the exact K stay fp64.
-// Streams 6 instead of 10 bytes per nonzero: 16-byte loads of 4 values + 8-byte loads of 4 indices, 4 in flight per lane.
-template <class Epi>
-__global__ __launch_bounds__(1024) void k_spmv_slab32(const int *__restrict__ done, int nrows, int ncols, int nslabs, int W,
-                                                      int rows_per_wg, const int2 *__restrict__ seg, const unsigned short *__restrict__ i16sm,
-                                                      const float *__restrict__ vsm32, const double *__restrict__ x, Epi epi) {
-    constexpr int TPR = 16;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ double sm[32];
-    __shared__ int next_row;
-    if (done && *done) return;
-    double *xs = lds;
-    double *acc = lds + W;
-    const int tid = threadIdx.x;
-    const int row0 = blockIdx.x * rows_per_wg;
-    const int R = min(rows_per_wg, nrows - row0);
-    for (int r = tid; r < R; r += SLAB_THREADS) acc[r] = 0.0;
-    const int lane = tid & (TPR - 1);
-    for (int s = 0; s < nslabs; s++) {
-        const int c0 = s * W;
-        const int cw = min(W, ncols - c0);
-        __syncthreads();
-        {
-            const int pairs = cw >> 1;
-            const double2 *src = reinterpret_cast<const double2 *>(x + c0);
-            double2 *dst = reinterpret_cast<double2 *>(xs);
-            for (int i = tid; i < pairs; i += SLAB_THREADS) dst[i] = src[i];
-            if ((cw & 1) && tid == 0) xs[cw - 1] = x[c0 + cw - 1];
-            if (tid == 0) next_row = 0;
-        }
-        __syncthreads();
-        const int gw = (tid & 63) / TPR;
-        for (;;) {
-            int base = 0;
-            if ((tid & 63) == 0) base = atomicAdd(&next_row, 64 / TPR);
-            base = __shfl(base, 0, 64);
-            if (base >= R) break;
-            const int r = base + gw;
-            if (r >= R) continue;
-            const int row = row0 + r;
-            const int2 sg = seg[(size_t)row * nslabs + s];
-            const int beg = sg.x, end = sg.x + sg.y;
-            const int kb = beg & ~3;
-            double sa[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) sa[u] = 0.0;
-            for (int k = kb + 4 * lane; k < end; k += 16 * TPR) {
-                float4 v[4]; ushort4 a[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int kk = k + u * 4 * TPR;
-                    const int kc = kk < end ? kk : kb;
-                    v[u] = *reinterpret_cast<const float4 *>(vsm32 + kc);
-                    a[u] = *reinterpret_cast<const ushort4 *>(i16sm + kc);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int kk = k + u * 4 * TPR;
-                    const double p0 = (double)v[u].x * xs[a[u].x], p1 = (double)v[u].y * xs[a[u].y];
-                    const double p2 = (double)v[u].z * xs[a[u].z], p3 = (double)v[u].w * xs[a[u].w];
-                    sa[4 * u]     += (kk >= beg && kk < end) ? p0 : 0.0;
-                    sa[4 * u + 1] += (kk + 1 >= beg && kk + 1 < end) ? p1 : 0.0;
-                    sa[4 * u + 2] += (kk + 2 >= beg && kk + 2 < end) ? p2 : 0.0;
-                    sa[4 * u + 3] += (kk + 3 < end) ? p3 : 0.0;
-                }
-            }
-            double t = 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; u++) t += sa[2 * u] + sa[2 * u + 1];
-#pragma unroll
-            for (int o = TPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, TPR);
-            if (lane == 0) acc[r] += t;
-        }
-    }
-    __syncthreads();
-    for (int r = tid; r < R; r += SLAB_THREADS) epi.row(row0 + r, acc[r]);
-    epi.finish(sm);
-}
-// slab pointers by binary search in each (column-sorted) row; also flags unsorted rows
-__global__ void k_build_slab_ptr(int nrows, const int *__restrict__ rp, const int *__restrict__ ci, int nslabs, int W,
-                                 int *__restrict__ sp, int *__restrict__ unsorted) {
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
-        const int b = rp[r], e = rp[r + 1];
-        int bad = 0;
-        for (int k = b + 1; k < e; k++) bad |= (ci[k] < ci[k - 1]);
-        if (bad) atomicOr(unsorted, 1);
-        int *o = sp + (size_t)r * (nslabs + 1);
-        for (int s = 0; s < nslabs; s++) {
-            const int target = s * W;
-            int lo = b, hi = e;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ci[mid] < target) lo = mid + 1; else hi = mid; }
-            o[s] = lo;
-        }
-        o[nslabs] = e;
-    }
-}
-
-// slab-major order of the segments of one workgroup's rows: t = s*R + r; exclusive scan of the lengths
-__global__ __launch_bounds__(1024) void k_slab_seg(int nrows, int nslabs, int rows_per_wg, const int *__restrict__ sp, int2 *__restrict__ seg) {
-    __shared__ int sums[1024];
-    const int row0 = blockIdx.x * rows_per_wg;
-    const int R = min(rows_per_wg, nrows - row0);
-    if (R <= 0) return;
-    const int T = R * nslabs, chunk = (T + 1023) / 1024;
-    const int t0 = min((int)threadIdx.x * chunk, T), t1 = min(t0 + chunk, T);
-    int c = 0;
-    for (int t = t0; t < t1; t++) { const int sl = t / R, r = t - sl * R; const int *q = sp + (size_t)(row0 + r) * (nslabs + 1) + sl; c += q[1] - q[0]; }
-    sums[threadIdx.x] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; i++) { const int v = sums[i]; sums[i] = run; run += v; } }
-    __syncthreads();
-    int pos = sp[(size_t)row0 * (nslabs + 1)] + sums[threadIdx.x];
-    for (int t = t0; t < t1; t++) {
-        const int sl = t / R, r = t - sl * R; const int *q = sp + (size_t)(row0 + r) * (nslabs + 1) + sl;
-        const int len = q[1] - q[0];
-        seg[(size_t)(row0 + r) * nslabs + sl] = make_int2(pos, len);
-        pos += len;
-    }
-}
-// copy values and slab-local indices of every (row, slab) segment to its slab-major place; 16 lanes per row
-__global__ __launch_bounds__(256) void k_slab_permute(int nrows, int nslabs, int W, const int *__restrict__ sp, const int2 *__restrict__ seg,
-                                                      const int *__restrict__ ci, const unsigned short *__restrict__ ci16,
-                                                      const double *__restrict__ val, double *__restrict__ vsm,
-                                                      unsigned short *__restrict__ i16sm, int *__restrict__ cism, float *__restrict__ vsm32) {
-    const int lane = threadIdx.x & 15;
-    const int ngroups = gridDim.x * (blockDim.x >> 4);
-    for (int row = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); row < nrows; row += ngroups)
-        for (int sl = 0; sl < nslabs; sl++) {
-            const int src = sp[(size_t)row * (nslabs + 1) + sl];
-            const int2 sg = seg[(size_t)row * nslabs + sl];
-            for (int e = lane; e < sg.y; e += 16) {
-                const double v = val[src + e];
-                vsm[sg.x + e] = v;
-                if (vsm32) vsm32[sg.x + e] = (float)v;
-                if (i16sm) i16sm[sg.x + e] = ci16[src + e]; else cism[sg.x + e] = ci[src + e] - sl * W;
-            }
-        }
-}
-
-struct EpiStore {                          // y = M x
-    double *y;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int r, double s) { y[r] = s; }
-    __device__ void finish(double *) {}
-};
-struct EpiRhs {                            // newton.c:42-45: Atdy = A' t ; rhs = -res_dual_in - Atdy
-    const double *rdi; double *atdy, *rhs;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int r, double s) { atdy[r] = s; rhs[r] = -rdi[r] - s; }
-    __device__ void finish(double *) {}
-};
-struct EpiQdx {                            // newton.c:52-55 + the two n-dots of linesearch.c:19-25
-    const double *dx, *df; double sigma; int prox; double *Qdx, *p_dxQdx, *p_dxdf;
-    double a1 = 0.0, a2 = 0.0;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int r, double s) {
-        double v = prox ? s + sigma * dx[r] : s;
-        Qdx[r] = v; a1 += dx[r] * v; a2 += dx[r] * df[r];
-    }
-    __device__ void finish(double *sm) {
-        double t1 = block_sum(a1, sm), t2 = block_sum(a2, sm + 16);
-        if (threadIdx.x == 0) { p_dxQdx[blockIdx.x] = t1; p_dxdf[blockIdx.x] = t2; }
-    }
-};
-struct EpiQpure {                          // qpdo.c:385: Qdx = Q dx (no sigma), warm start Qx
-    const double *xv; double sigma; int prox; double *out;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int r, double s) { out[r] = prox ? s + sigma * xv[r] : s; }
-    __device__ void finish(double *) {}
-};
-// A*dx with the m-side of newton.c:57-63 and linesearch.c:13-40,82-120 fused behind it
-struct EpiAdxLs {
-    int m;
-    const double *mu, *isq, *w, *l, *u, *y; const int *active; int *active_old;
-    double *Adx, *dy, *delta, *alpha; u64 *key; u32 *idx;
-    double *p_eta, *p_beta, *p_a0, *p_b0; Ctrl *ctrl;
-    double e = 0.0, b = 0.0, a0 = 0.0, b0 = 0.0; int nL = 0;
-    __device__ bool skip(int) const { return false; }
-    __device__ void cand(int i, double dl, double al) {
-        delta[i] = dl; alpha[i] = al;
-        const double t = al / dl;
-        const bool L = t > 0, P = dl > 0;
-        key[i] = L ? (u64)__double_as_longlong(t) : KEY_SENTINEL;
-        idx[i] = (u32)i;
-        if (L) nL++;
-        if (L != P) { a0 += dl * dl; b0 += dl * al; }
-    }
-    __device__ void row(int r, double s) {
-        Adx[r] = s;
-        const int act = active[r];
-        double dyr = dy[r];
-        if (act) dyr += s / mu[r];
-        dy[r] = dyr;
-        active_old[r] = act;                       // newton.c:69
-        double sv = dyr * mu[r]; sv = sv * 0.5;    // linesearch.c:14-15
-        e += dyr * sv; b += y[r] * sv;
-        double c0 = s - sv; c0 = c0 * isq[r];      // linesearch.c:27-28
-        const double dlo = c0 * -1.0;
-        const double alo = (w[r] - l[r]) * isq[r];
-        const double ahi = (u[r] - w[r]) * isq[r];
-        cand(r, dlo, alo);
-        cand(r + m, c0, ahi);
-    }
-    __device__ void finish(double *sm) {
-        double t1 = block_sum(e, sm), t2 = block_sum(b, sm + 16);
-        double t3 = block_sum(a0, sm), t4 = block_sum(b0, sm + 16);
-        int tn = block_sum_int(nL, (int *)sm);
-        if (threadIdx.x == 0) {
-            p_eta[blockIdx.x] = t1; p_beta[blockIdx.x] = t2; p_a0[blockIdx.x] = t3; p_b0[blockIdx.x] = t4;
-            if (tn) atomicAdd(&ctrl->cnt[C_NL], tn);
-        }
-    }
-};
-struct EpiPcgA {                           // t = d_c .* (A_c p) in the compact row space of the pass
-    const double *d; double *t; const int *done;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int r, double s) { t[r] = d[r] * s; }
-    __device__ void finish(double *) {}
-};
-struct EpiPcgQ {                           // Kp = Q p + sigma_f p
-    const double *p; double sigma_f; double *Kp;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int r, double s) { Kp[r] = s + sigma_f * p[r]; }
-    __device__ void finish(double *) {}
-};
-struct EpiPcgQdot {                        // no weighted rows: Kp = Q p + sigma_f p and the p.Kp partials in one go
-    const double *p; double sigma_f; double *Kp, *p_pKp; double acc = 0.0;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int r, double s) { const double v = s + sigma_f * p[r]; Kp[r] = v; acc += p[r] * v; }
-    __device__ void finish(double *sm) {
-        double t = block_sum(acc, sm);
-        if (threadIdx.x == 0) p_pKp[blockIdx.x] = t;
-    }
-};
-struct EpiPcgAt {                          // Kp += A' t ; partial p.Kp
-    const double *p; double *Kp, *p_pKp; double acc = 0.0;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int r, double s) { double v = Kp[r] + s; Kp[r] = v; acc += p[r] * v; }
-    __device__ void finish(double *sm) {
-        double t = block_sum(acc, sm);
-        if (threadIdx.x == 0) p_pKp[blockIdx.x] = t;
-    }
-};
-struct EpiDivStore {                       // out = (M x) ./ w
-    const double *w; double *out;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int r, double s) { out[r] = s / w[r]; }
-    __device__ void finish(double *) {}
-};
-struct EpiSchurA {                         // Sp = p ./ d + A_c t ; partial p.Sp   (S' = D^-1 + A_c Dq^-1 A_c')
-    const double *dc, *p; double *Sp, *p_pSp; double acc = 0.0;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int r, double s) { const double v = p[r] / dc[r] + s; Sp[r] = v; acc += p[r] * v; }
-    __device__ void finish(double *sm) {
-        double t = block_sum(acc, sm);
-        if (threadIdx.x == 0) p_pSp[blockIdx.x] = t;
-    }
-};
-struct EpiResid {                          // r = rhs - (Kp + A' t), ||r||inf -> ctrl->nrm[slot] (inf if any NaN)
-    const double *rhs, *Kp; double *r; Ctrl *ctrl; int slot; double mx = 0.0;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int j, double s) {
-        const double v = rhs[j] - (Kp[j] + s);
-        r[j] = v;
-        const double a = fabs(v);
-        mx = (v != v) ? __longlong_as_double(0x7FF0000000000000LL) : (a > mx ? a : mx);
-    }
-    __device__ void finish(double *sm) { block_max_to(mx, &ctrl->nrm[slot], sm); }
-};
-
-static inline int spmv_grid(const DevCsr &M, int tpr, bool partials) {
-    if (M.use_slab) return M.slab_grid;
-    long long groups_per_block = BLK / tpr;
-    long long g = (M.nrows + groups_per_block - 1) / groups_per_block;
-    long long cap = partials ? PGRID : 4096;
-    if (g > cap) g = cap;
-    if (g < 1) g = 1;
-    return (int)g;
-}
-// (re)build the slab-major image of M from its row-major arrays and slab pointers
-static void slab_major_build(QpdoDev *d, const DevCsr &M);
-template <class Epi>
-static void launch_spmv_slab(QpdoDev *d, const DevCsr &M, const double *x, Epi epi, const int *done) {
-    const size_t lds = ((size_t)M.W + (size_t)M.rows_per_wg) * sizeof(double);
-    static thread_local bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-#define SLAB_ATTR(I16, T) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab<Epi, I16, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)
-        SLAB_ATTR(false, 8); SLAB_ATTR(false, 16); SLAB_ATTR(false, 32); SLAB_ATTR(true, 8); SLAB_ATTR(true, 16); SLAB_ATTR(true, 32);
-#undef SLAB_ATTR
-        attr_set = true;
-    }
-    if (M.sm_dirty) slab_major_build(d, M);
-#define SLAB_GO(I16, T) hipLaunchKernelGGL((k_spmv_slab<Epi, I16, T>), dim3(M.slab_grid), dim3(SLAB_THREADS), lds, d->stream, done, M.nrows, M.ncols, M.nslabs, M.W, M.rows_per_wg, M.seg, M.cism, M.i16sm, M.vsm, x, epi)
-    if (M.i16sm) { if (g_slab_tpr == 8) SLAB_GO(true, 8); else if (g_slab_tpr == 32) SLAB_GO(true, 32); else SLAB_GO(true, 16); }
-    else        { if (g_slab_tpr == 8) SLAB_GO(false, 8); else if (g_slab_tpr == 32) SLAB_GO(false, 32); else SLAB_GO(false, 16); }
-#undef SLAB_GO
-    d->st.spmv_calls++;
-    d->st.spmv_bytes += (int64_t)M.alg_bytes();
-}
-template <class Epi>
-static void launch_spmv_slab32(QpdoDev *d, const DevCsr &M, const double *x, Epi epi, const int *done) {
-    const size_t lds = ((size_t)M.W + (size_t)M.rows_per_wg) * sizeof(double);
-    static thread_local bool attr_set = false;   // per instantiation
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_slab32<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr_set = true; }
-    if (M.sm_dirty) slab_major_build(d, M);
-    hipLaunchKernelGGL((k_spmv_slab32<Epi>), dim3(M.slab_grid), dim3(SLAB_THREADS), lds, d->stream, done, M.nrows, M.ncols, M.nslabs, M.W, M.rows_per_wg,
-                       (const int2 *)M.seg, (const unsigned short *)M.i16sm, (const float *)M.vsm32, x, epi);
-    d->st.spmv_calls++;
-    d->st.spmv_bytes += (int64_t)M.alg_bytes();
-}
-template <class Epi>
-static void launch_spmv(QpdoDev *d, const DevCsr &M, const double *x, Epi epi, bool partials) {
-    const int g = spmv_grid(M, M.tpr, partials);
-    if (M.use_slab) { launch_spmv_slab(d, M, x, epi, (const int *)nullptr); return; }
-    switch (M.tpr) {
-        case 4:  hipLaunchKernelGGL((k_spmv<4, Epi>),  dim3(g), dim3(BLK), 0, d->stream, M.nrows, M.rp, M.ci, M.val, x, epi); break;
-        case 8:  hipLaunchKernelGGL((k_spmv<8, Epi>),  dim3(g), dim3(BLK), 0, d->stream, M.nrows, M.rp, M.ci, M.val, x, epi); break;
-        case 16: hipLaunchKernelGGL((k_spmv<16, Epi>), dim3(g), dim3(BLK), 0, d->stream, M.nrows, M.rp, M.ci, M.val, x, epi); break;
-        case 32: hipLaunchKernelGGL((k_spmv<32, Epi>), dim3(g), dim3(BLK), 0, d->stream, M.nrows, M.rp, M.ci, M.val, x, epi); break;
-        default: hipLaunchKernelGGL((k_spmv<64, Epi>), dim3(g), dim3(BLK), 0, d->stream, M.nrows, M.rp, M.ci, M.val, x, epi); break;
-    }
-    d->st.spmv_calls++;
-    d->st.spmv_bytes += (int64_t)M.alg_bytes();
-}
-// number of blocks a partial-emitting spmv launch uses (consumers need it)
-static inline int spmv_pgrid(const DevCsr &M) { return spmv_grid(M, M.tpr, true); }
-
-// PCG variant: identical body, but every thread leaves at once when the solver has converged.
-template <int TPR, class Epi>
-__global__ __launch_bounds__(256) void k_spmv_pcg(const int *__restrict__ done, int nrows, const int *__restrict__ rp,
-                                                  const int *__restrict__ ci, const double *__restrict__ val,
-                                                  const double *__restrict__ x, Epi epi) {
-    __shared__ double sm[32];
-    if (*done) return;
-    const int lane = threadIdx.x % TPR;
-    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
-    const int ngroups = gridDim.x * (BLK / TPR);
-    for (int row = group; row < nrows; row += ngroups) {
-        double s = 0.0;
-        if (!epi.skip(row)) {
-            const int beg = rp[row], end = rp[row + 1];
-            double s0 = 0.0, s1 = 0.0;
-            int k = beg + lane;
-            for (; k + TPR < end; k += 2 * TPR) {
-                const double v0 = val[k], v1 = val[k + TPR];
-                const int c0 = ci[k], c1 = ci[k + TPR];
-                s0 += v0 * x[c0];
-                s1 += v1 * x[c1];
-            }
-            if (k < end) s0 += val[k] * x[ci[k]];
-            s = group_sum<TPR>(s0 + s1);
-        }
-        if (lane == 0) epi.row(row, s);
-    }
-    epi.finish(sm);
-}
-template <class Epi>
-static void launch_spmv_pcg(QpdoDev *d, const DevCsr &M, const double *x, Epi epi, bool partials, const int *latch = nullptr) {
-    const int g = spmv_grid(M, M.tpr, partials);
-    const int *done = latch ? latch : &d->ctrl->cnt[C_PCG_DONE];
-    if (M.use_slab) { launch_spmv_slab(d, M, x, epi, done); return; }
-    switch (M.tpr) {
-        case 4:  hipLaunchKernelGGL((k_spmv_pcg<4, Epi>),  dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
-        case 8:  hipLaunchKernelGGL((k_spmv_pcg<8, Epi>),  dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
-        case 16: hipLaunchKernelGGL((k_spmv_pcg<16, Epi>), dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
-        case 32: hipLaunchKernelGGL((k_spmv_pcg<32, Epi>), dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
-        default: hipLaunchKernelGGL((k_spmv_pcg<64, Epi>), dim3(g), dim3(BLK), 0, d->stream, done, M.nrows, M.rp, M.ci, M.val, x, epi); break;
-    }
-    d->st.spmv_calls++;
-    d->st.spmv_bytes += (int64_t)M.alg_bytes();
-}
-
-// row-wise max |a_ij| (Ruiz norms, cholmod_interface.c:162-199) -- one lane group per row
-template <int TPR>
-__global__ __launch_bounds__(256) void k_row_absmax(int nrows, const int *__restrict__ rp, const double *__restrict__ val,
-                                                    double *__restrict__ out) {
-    const int lane = threadIdx.x % TPR;
-    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
-    const int ngroups = gridDim.x * (BLK / TPR);
-    for (int row = group; row < nrows; row += ngroups) {
-        double mx = 0.0;
-        for (int k = rp[row] + lane; k < rp[row + 1]; k += TPR) mx = absmax_acc(mx, val[k]);
-#pragma unroll
-        for (int o = TPR / 2; o > 0; o >>= 1) { double t = __shfl_down(mx, o, TPR); mx = t > mx ? t : mx; }
-        if (lane == 0) out[row] = mx;
-    }
-}
-// val[k] = (val[k] * rs[row or col]) * cs[...]: ROW scale then COL scale (scaling.c:56-57)
-template <int TPR>
-__global__ __launch_bounds__(256) void k_scale_rows_cols(int nrows, const int *__restrict__ rp, const int *__restrict__ ci,
-                                                         double *__restrict__ val, const double *__restrict__ first_by_row,
-                                                         const double *__restrict__ first_by_col,
-                                                         const double *__restrict__ second_by_row,
-                                                         const double *__restrict__ second_by_col) {
-    const int lane = threadIdx.x % TPR;
-    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
-    const int ngroups = gridDim.x * (BLK / TPR);
-    for (int row = group; row < nrows; row += ngroups) {
-        for (int k = rp[row] + lane; k < rp[row + 1]; k += TPR) {
-            double v = val[k];
-            v = v * (first_by_row ? first_by_row[row] : first_by_col[ci[k]]);
-            v = v * (second_by_row ? second_by_row[row] : second_by_col[ci[k]]);
-            val[k] = v;
-        }
-    }
-}
-// Q <- D Q D: val *= (D[col] * D[row]) for a stored lower entry (row i, col j): t = s[j]; x *= t*s[i]
-template <int TPR>
-__global__ __launch_bounds__(256) void k_scale_sym(int nrows, const int *__restrict__ rp, const int *__restrict__ ci,
-                                                   double *__restrict__ val, const double *__restrict__ D) {
-    const int lane = threadIdx.x % TPR;
-    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
-    const int ngroups = gridDim.x * (BLK / TPR);
-    for (int row = group; row < nrows; row += ngroups) {
-        for (int k = rp[row] + lane; k < rp[row + 1]; k += TPR) {
-            const int c = ci[k];
-            // lower entry (i>=j) is stored as (row=i,col=j): t = D[j] * D[i]; its mirror computes the same product
-            const double t = row >= c ? D[c] * D[row] : D[row] * D[c];
-            val[k] *= t;
-        }
-    }
-}
-__global__ void k_scale_sym_rows(int nrows, int row0, const int *__restrict__ rp, const int *__restrict__ ci, double *__restrict__ val,
-                                 const double *__restrict__ D) {
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
-        const int row = r + row0;
-        for (int k = rp[r]; k < rp[r + 1]; k++) { const int c = ci[k]; val[k] *= (row >= c ? D[c] * D[row] : D[row] * D[c]); }
-    }
-}
-__global__ void k_scale_vals(long long nnz, double *__restrict__ val, double f) {
-    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) val[k] *= f;
-}
-// Jacobi diagonal: diag_j = Q_jj + sigma_f + sum_i A_ij^2 d_i  (row j of CSR(A'))
-template <int TPR>
-__global__ __launch_bounds__(256) void k_jacobi_diag(int n, const int *__restrict__ rp, const int *__restrict__ ci,
-                                                     const double *__restrict__ val, const double *__restrict__ dw,
-                                                     const double *__restrict__ qdiag, double sigma_f, double *__restrict__ out) {
-    const int lane = threadIdx.x % TPR;
-    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
-    const int ngroups = gridDim.x * (BLK / TPR);
-    for (int row = group; row < n; row += ngroups) {
-        double s = 0.0;
-        for (int k = rp[row] + lane; k < rp[row + 1]; k += TPR) { double v = val[k]; s += v * v * dw[ci[k]]; }
-        s = group_sum<TPR>(s);
-        if (lane == 0) out[row] = qdiag[row] + sigma_f + s;
-    }
-}
-// deflated variant: P_j = max(remainder_j, 1e-6 * full_j).  The floor bounds the cancellation in the Woodbury
-// form u - P^-1 A_h' S^-1 A_h u to six digits; M = P + A_h' D_h A_h stays SPD, which is all PCG requires.
-template <int TPR>
-__global__ __launch_bounds__(256) void k_jacobi_diag2(int n, const int *__restrict__ rp, const int *__restrict__ ci,
-                                                      const double *__restrict__ val, const double *__restrict__ dlight,
-                                                      const double *__restrict__ dfull, const double *__restrict__ qdiag,
-                                                      double sigma_f, double *__restrict__ out) {
-    const int lane = threadIdx.x % TPR;
-    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
-    const int ngroups = gridDim.x * (BLK / TPR);
-    for (int row = group; row < n; row += ngroups) {
-        double s = 0.0, f = 0.0;
-        for (int k = rp[row] + lane; k < rp[row + 1]; k += TPR) { const double v = val[k]; const int c = ci[k]; s += v * v * dlight[c]; f += v * v * dfull[c]; }
-        s = group_sum<TPR>(s); f = group_sum<TPR>(f);
-        if (lane == 0) {
-            const double rem = qdiag[row] + sigma_f + s, full = qdiag[row] + sigma_f + f;
-            out[row] = rem > 1e-6 * full ? rem : 1e-6 * full;
-        }
-    }
-}
-// diagonal of the inner system of the Schur mode: Sd_i = 1/d_i + sum_j A_ij^2 / Dq_j  (row i of the compact A_c)
-template <int TPR>
-__global__ __launch_bounds__(256) void k_schur_diag(int k, const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
-                                                    const double *__restrict__ Dq, const double *__restrict__ dc, double *__restrict__ out) {
-    const int lane = threadIdx.x % TPR;
-    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
-    const int ngroups = gridDim.x * (BLK / TPR);
-    for (int row = group; row < k; row += ngroups) {
-        double s = 0.0;
-        for (int e = rp[row] + lane; e < rp[row + 1]; e += TPR) { const double v = val[e]; s += v * v / Dq[ci[e]]; }
-        s = group_sum<TPR>(s);
-        if (lane == 0) out[row] = 1.0 / dc[row] + s;
-    }
-}
-__global__ void k_extract_diag(int n, const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
-                               double *__restrict__ out) {
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        double dg = 0.0;
-        for (int k = rp[r]; k < rp[r + 1]; k++) if (ci[k] == r) dg += val[k];
-        out[r] = dg;
-    }
-}
-
-// compact index space of a Newton pass: cidx[i] = number of weighted rows before i, rowlist = their ids (single block)
-__global__ __launch_bounds__(1024) void k_flag_scan(int m, const double *__restrict__ dw, int *__restrict__ cidx, int *__restrict__ rowlist,
-                                                    int *__restrict__ count) {
-    __shared__ int sums[1024];
-    const int chunk = (m + 1023) / 1024;
-    const int beg = threadIdx.x * chunk, end = min(beg + chunk, m);
-    int c = 0;
-    for (int i = beg; i < end; i++) c += (dw[i] != 0.0);
-    sums[threadIdx.x] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; i++) { int t = sums[i]; sums[i] = run; run += t; } *count = run; }
-    __syncthreads();
-    int pos = sums[threadIdx.x];
-    for (int i = beg; i < end; i++) { cidx[i] = pos; if (dw[i] != 0.0) { rowlist[pos] = i; pos++; } }
-}
-__global__ void k_gather_rowinfo(int k, const int *__restrict__ rowlist, const int *__restrict__ rp, const double *__restrict__ dw,
-                                 int *__restrict__ cnt, double *__restrict__ dc) {
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x) {
-        const int r = rowlist[j];
-        cnt[j] = rp[r + 1] - rp[r]; dc[j] = dw[r];
-    }
-}
-// copy the listed rows of a CSR matrix into a contiguous CSR (one wave per row)
-__global__ __launch_bounds__(256) void k_copy_rows(int k, const int *__restrict__ rowlist, const int *__restrict__ rp, const int *__restrict__ ci,
-                                                   const unsigned short *__restrict__ ci16, const double *__restrict__ val,
-                                                   const int *__restrict__ rp2, int *__restrict__ ci2, unsigned short *__restrict__ ci16_2,
-                                                   double *__restrict__ val2) {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * BLK + threadIdx.x) >> 6;
-    const int nwaves = gridDim.x * (BLK >> 6);
-    for (int j = wave; j < k; j += nwaves) {
-        const int r = rowlist[j];
-        const int src = rp[r], len = rp[r + 1] - src, dst = rp2[j];
-        for (int e = lane; e < len; e += 64) {
-            ci2[dst + e] = ci[src + e]; val2[dst + e] = val[src + e];
-            if (ci16) ci16_2[dst + e] = ci16[src + e];
-        }
-    }
-}
-__global__ void k_fill_ci16(long long nnz, const int *__restrict__ ci, int W, unsigned short *__restrict__ ci16) {
-    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x)
-        ci16[k] = (unsigned short)(ci[k] % W);
-}
-// ---- per-pass compaction of CSR(A') to the columns (constraints) that carry weight ------------------
-// Rows of A with d_i == 0 contribute exact zeros to A' (d .* (A p)); dropping those entries from the
-// n x m CSR once per Newton pass removes their HBM traffic from every PCG iteration.  Order inside a
-// row is preserved (stable ballot compaction), so the product stays reproducible.
-template <int TPR>
-__global__ __launch_bounds__(256) void k_count_flagged(int nrows, const int *__restrict__ rp, const int *__restrict__ ci,
-                                                       const double *__restrict__ dw, int *__restrict__ cnt) {
-    const int lane = threadIdx.x % TPR;
-    const int group = (blockIdx.x * BLK + threadIdx.x) / TPR;
-    const int ngroups = gridDim.x * (BLK / TPR);
-    for (int row = group; row < nrows; row += ngroups) {
-        int c = 0;
-        for (int k = rp[row] + lane; k < rp[row + 1]; k += TPR) c += (dw[ci[k]] != 0.0);
-#pragma unroll
-        for (int o = TPR / 2; o > 0; o >>= 1) c += __shfl_down(c, o, TPR);
-        if (lane == 0) cnt[row] = c;
-    }
-}
-// exclusive scan of cnt[0..n) into out[0..n] by one block (n up to a few 1e5)
-__global__ __launch_bounds__(1024) void k_scan_counts(const int *__restrict__ cnt, int n, int *__restrict__ out) {
-    __shared__ int sums[1024];
-    const int chunk = (n + 1023) / 1024;
-    const int beg = threadIdx.x * chunk, end = min(beg + chunk, n);
-    int s = 0;
-    for (int i = beg; i < end; i++) s += cnt[i];
-    sums[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; i++) { int t = sums[i]; sums[i] = run; run += t; } out[n] = run; }
-    __syncthreads();
-    int run = sums[threadIdx.x];
-    for (int i = beg; i < end; i++) { out[i] = run; run += cnt[i]; }
-}
-// one wave per row: stable compaction of (ci, val) pairs whose column weight is nonzero; kept columns are
-// renumbered through `remap` (monotone, so rows stay column-sorted) and, if W16 > 0, their slab-local
-// 16-bit index is produced as well
-__global__ __launch_bounds__(256) void k_compact_rows(int nrows, const int *__restrict__ rp, const int *__restrict__ ci,
-                                                      const double *__restrict__ val, const double *__restrict__ dw,
-                                                      const int *__restrict__ rp2, int *__restrict__ ci2, double *__restrict__ val2,
-                                                      const int *__restrict__ remap, int W16, unsigned short *__restrict__ ci16) {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * BLK + threadIdx.x) >> 6;
-    const int nwaves = gridDim.x * (BLK >> 6);
-    for (int row = wave; row < nrows; row += nwaves) {
-        const int beg = rp[row], end = rp[row + 1];
-        int base = rp2[row];
-        for (int k0 = beg; k0 < end; k0 += 64) {
-            const int k = k0 + lane;
-            int c = 0; double v = 0.0; bool keep = false;
-            if (k < end) { c = ci[k]; v = val[k]; keep = dw[c] != 0.0; }
-            const u64 bal = __ballot(keep);
-            if (keep) {
-                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                const int cn = remap ? remap[c] : c;
-                ci2[pos] = cn; val2[pos] = v;
-                if (W16 > 0) ci16[pos] = (unsigned short)(cn % W16);
-            }
-            base += __popcll(bal);
-        }
-    }
-}
-
-#define DISPATCH_TPR(M, KERNEL, GRID, ...)                                                                  \
-    switch ((M).tpr) {                                                                                      \
-        case 4:  hipLaunchKernelGGL((KERNEL<4>),  dim3(GRID), dim3(BLK), 0, d->stream, __VA_ARGS__); break; \
-        case 8:  hipLaunchKernelGGL((KERNEL<8>),  dim3(GRID), dim3(BLK), 0, d->stream, __VA_ARGS__); break; \
-        case 16: hipLaunchKernelGGL((KERNEL<16>), dim3(GRID), dim3(BLK), 0, d->stream, __VA_ARGS__); break; \
-        case 32: hipLaunchKernelGGL((KERNEL<32>), dim3(GRID), dim3(BLK), 0, d->stream, __VA_ARGS__); break; \
-        default: hipLaunchKernelGGL((KERNEL<64>), dim3(GRID), dim3(BLK), 0, d->stream, __VA_ARGS__); break; \
-    }
-
-// ------------------------------------------------------------------------------------------------
-// vector kernels
-// ------------------------------------------------------------------------------------------------
-__global__ void k_ctrl_clear_pass(Ctrl *c) {
-    const int t = threadIdx.x;
-    if (t < 4) c->nrm[t] = 0ull;
-    if (t >= 8 && t < 11) c->cnt[t - 8] = 0;
-}
-__global__ void k_ctrl_clear_aux(Ctrl *c) {
-    const int t = threadIdx.x;
-    if (t < 4) c->nrm[N_A + t] = 0ull;
-    if (t == 4) c->cnt[C_MUCH] = 0;
-    if (t == 5) c->cnt[C_VIOL] = 0;
-}
-
-// m-side of iteration.c:30-47,65-81, termination.c:39-41,62-64 and newton.c:96-126 in one pass
-__global__ __launch_bounds__(256) void k_resid_m(int m, int scaled, double cinv, const double *__restrict__ Ax,
-                                                 const double *__restrict__ y, const double *__restrict__ ybar,
-                                                 const double *__restrict__ mu, const double *__restrict__ l,
-                                                 const double *__restrict__ u, const double *__restrict__ E,
-                                                 const double *__restrict__ Einv, double *__restrict__ res_prim,
-                                                 double *__restrict__ w, double *__restrict__ res_prim_in,
-                                                 int *__restrict__ active, const int *__restrict__ active_old, Ctrl *ctrl) {
-    __shared__ double sm[32];
-    double mx1 = 0.0, mx2 = 0.0; int na = 0, ne = 0, nl = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        const double ax = Ax[i], yi = y[i], li = l[i], ui = u[i], mui = mu[i], yb = ybar[i];
-        double t;
-        if (scaled) { t = E[i] * yi; t = t * cinv; t = E[i] * t; t = ax + t; }
-        else t = ax + yi;
-        const double z = mid3(t, li, ui);
-        const double rp = ax - z;
-        res_prim[i] = rp;
-        const double wi = ax + mui * (yb - 0.5 * yi);
-        w[i] = wi;
-        const double zin = mid3(wi, li, ui);
-        const double rpi = ax + mui * (yb - yi) - zin;
-        res_prim_in[i] = rpi;
-        const int act = (wi <= li) || (wi >= ui);
-        active[i] = act;
-        const int old = active_old[i];
-        na += act; ne += (act && !old); nl += (!act && old);
-        mx1 = absmax_acc(mx1, scaled ? Einv[i] * rp : rp);
-        mx2 = absmax_acc(mx2, scaled ? Einv[i] * rpi : rpi);
-    }
-    block_max_to(mx1, &ctrl->nrm[N_PRIM], sm);
-    block_max_to(mx2, &ctrl->nrm[N_PRIM_IN], sm + 16);
-    int ta = block_sum_int(na, (int *)sm), te = block_sum_int(ne, (int *)sm), tl = block_sum_int(nl, (int *)sm);
-    if (threadIdx.x == 0) {
-        if (ta) atomicAdd(&ctrl->cnt[C_ACTIVE], ta);
-        if (te) atomicAdd(&ctrl->cnt[C_ENTER], te);
-        if (tl) atomicAdd(&ctrl->cnt[C_LEAVE], tl);
-    }
-}
-// n-side of iteration.c:48-59,82-92 and termination.c:43-45,69-72
-__global__ __launch_bounds__(256) void k_resid_n(int n, int scaled, int prox, double sigma, const double *__restrict__ Qx,
-                                                 const double *__restrict__ q, const double *__restrict__ x,
-                                                 const double *__restrict__ xbar, const double *__restrict__ Aty,
-                                                 const double *__restrict__ Dinv, double *__restrict__ df,
-                                                 double *__restrict__ res_dual, double *__restrict__ res_dual_in, Ctrl *ctrl) {
-    __shared__ double sm[32];
-    double mx1 = 0.0, mx2 = 0.0;
-    const double ns = -sigma;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const double df0 = Qx[j] + q[j], aty = Aty[j];
-        double rd, dfi;
-        if (prox) { rd = df0 + ns * x[j]; rd = rd + aty; dfi = df0 + ns * xbar[j]; }
-        else { rd = df0 + aty; dfi = df0; }
-        const double rdi = dfi + aty;
-        df[j] = dfi; res_dual[j] = rd; res_dual_in[j] = rdi;
-        mx1 = absmax_acc(mx1, scaled ? Dinv[j] * rd : rd);
-        mx2 = absmax_acc(mx2, scaled ? Dinv[j] * rdi : rdi);
-    }
-    block_max_to(mx1, &ctrl->nrm[N_DUAL], sm);
-    block_max_to(mx2, &ctrl->nrm[N_DUAL_IN], sm + 16);
-}
-
-// factor-state weights d (cholmod_interface.c:35-72 as rules on d) + t = (I+P) res_prim_in ./ mu (newton.c:37-40)
-__global__ void k_newton_prep(int m, int branch, const int *__restrict__ active, const int *__restrict__ active_old,
-                              const double *__restrict__ isq, const double *__restrict__ mu,
-                              const double *__restrict__ res_prim_in, double *__restrict__ d, double *__restrict__ dy) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        const int act = active[i], old = active_old[i];
-        const double wgt = isq[i] * isq[i];
-        if (branch == 0) d[i] = act ? wgt : 0.0;
-        else if (branch == 1) { if (act && !old) d[i] += wgt; else if (!act && old) d[i] -= wgt; }
-        else d[i] = 0.0;
-        double t = res_prim_in[i] / mu[i];
-        if (!act) t *= 2;
-        dy[i] = t;
-    }
-}
-
-// iteration.c:19-24: five axpys with tau read from the control block
-__global__ void k_axpy5(int n, int m, const Ctrl *__restrict__ ctrl, double *__restrict__ x, const double *__restrict__ dx,
-                        double *__restrict__ Qx, const double *__restrict__ Qdx, double *__restrict__ Aty,
-                        const double *__restrict__ Atdy, double *__restrict__ y, const double *__restrict__ dy,
-                        double *__restrict__ Ax, const double *__restrict__ Adx) {
-    const double tau = ctrl->val[V_TAU];
-    const int tot = n > m ? n : m;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += gridDim.x * blockDim.x) {
-        if (i < n) { x[i] = x[i] + tau * dx[i]; Qx[i] = Qx[i] + tau * Qdx[i]; Aty[i] = Aty[i] + tau * Atdy[i]; }
-        if (i < m) { y[i] = y[i] + tau * dy[i]; Ax[i] = Ax[i] + tau * Adx[i]; }
-    }
-}
-__global__ void k_sub(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ c) {  // c = a + (-1) b
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c[i] = a[i] - b[i];
-}
-__global__ void k_axpy(int n, double sc, const double *__restrict__ b, double *__restrict__ a) {   // a = a + sc b
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = a[i] + sc * b[i];
-}
-__global__ void k_axpy_const(int n, const double *__restrict__ a, double c, double *__restrict__ out) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = a[i] + c;
-}
-__global__ void k_mul(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ c) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c[i] = a[i] * b[i];
-}
-__global__ void k_scal(int n, double sc, double *__restrict__ a) {   // a *= sc (lin_alg.c:45-50)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] *= sc;
-}
-__global__ void k_fill(int n, double v, double *__restrict__ a) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = v;
-}
-__global__ void k_fill_int(int n, int v, int *__restrict__ a) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = v;
-}
-// Ruiz: limit (<1e-9 -> 1), sqrt, reciprocal, accumulate into total (scaling.c:44-61)
-__global__ void k_ruiz_factor(int n, double *__restrict__ t, double *__restrict__ total) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        double v = t[i];
-        v = v < 1e-9 ? 1.0 : v;
-        v = sqrt(v);
-        v = 1.0 / v;
-        t[i] = v;
-        total[i] = total[i] * v;
-    }
-}
-__global__ void k_recip(int n, const double *__restrict__ a, double *__restrict__ b) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) b[i] = 1.0 / a[i];
-}
-// max |a + sc*b| into ctrl->nrm[slot]
-__global__ __launch_bounds__(256) void k_absmax_axpy(int n, const double *__restrict__ a, const double *__restrict__ b, double sc,
-                                                     Ctrl *ctrl, int slot) {
-    __shared__ double sm[32];
-    double mx = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        mx = absmax_acc(mx, b ? a[i] + sc * b[i] : a[i]);
-    block_max_to(mx, &ctrl->nrm[slot], sm);
-}
-__global__ __launch_bounds__(256) void k_absmax_mul(int n, const double *__restrict__ a, const double *__restrict__ b,
-                                                    Ctrl *ctrl, int slot) {
-    __shared__ double sm[32];
-    double mx = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        mx = absmax_acc(mx, b ? a[i] * b[i] : a[i]);
-    block_max_to(mx, &ctrl->nrm[slot], sm);
-}
-
-// warm start pieces (qpdo.c:238-279)
-__global__ void k_ws_x(int n, int scaled, const double *__restrict__ xin, const double *__restrict__ Dinv,
-                       double *__restrict__ x, double *__restrict__ xbar) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        double v = xin[i];
-        if (scaled) v = v * Dinv[i];
-        x[i] = v; xbar[i] = v;
-    }
-}
-__global__ void k_ws_y(int m, int scaled, double c, const double *__restrict__ yin, const double *__restrict__ Einv,
-                       double *__restrict__ y, double *__restrict__ ybar) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        double v = yin[i];
-        if (scaled) { v = v * Einv[i]; v = v * c; }
-        y[i] = v; ybar[i] = v;
-    }
-}
-// partial dots for f = 0.5 x'Qx + q'x (iteration.c:102) and the objective (iteration.c:185-221)
-__global__ __launch_bounds__(256) void k_dots_f(int n, const double *__restrict__ x, const double *__restrict__ Qx,
-                                                const double *__restrict__ q, double *__restrict__ p1, double *__restrict__ p2) {
-    __shared__ double sm[32];
-    double a = 0.0, b = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { a += x[i] * Qx[i]; b += q[i] * x[i]; }
-    double ta = block_sum(a, sm), tb = block_sum(b, sm + 16);
-    if (threadIdx.x == 0) { p1[blockIdx.x] = ta; p2[blockIdx.x] = tb; }
-}
-__global__ __launch_bounds__(256) void k_objective(int n, int prox, double sigma, const double *__restrict__ x,
-                                                   const double *__restrict__ Qx, const double *__restrict__ q,
-                                                   double *__restrict__ p) {
-    __shared__ double sm[32];
-    double a = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        a += prox ? (0.5 * (Qx[i] - x[i] * sigma) + q[i]) * x[i] : (0.5 * Qx[i] + q[i]) * x[i];
-    double t = block_sum(a, sm);
-    if (threadIdx.x == 0) p[blockIdx.x] = t;
-}
-__global__ __launch_bounds__(256) void k_reduce_to_ctrl(const double *__restrict__ p, int cnt, Ctrl *ctrl, int slot) {
-    __shared__ double sm[32];
-    double t = reduce_partials(p, cnt, sm);
-    if (threadIdx.x == 0) ctrl->val[slot] = t;
-}
-// iteration.c:98-122
-__global__ __launch_bounds__(256) void k_init_mu(int m, const double *__restrict__ p1, const double *__restrict__ p2, int pcnt,
-                                                 const double *__restrict__ Ax, const double *__restrict__ l,
-                                                 const double *__restrict__ u, double *__restrict__ mu, double *__restrict__ isq) {
-    __shared__ double sm[32];
-    const double xQx = reduce_partials(p1, pcnt, sm), qx = reduce_partials(p2, pcnt, sm + 16);
-    const double f = 0.5 * xQx + qx;
-    const double af = f < 0 ? -f : f;
-    const double den = 1 > af ? 1 : af;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        const double ax = Ax[i];
-        const double r = ax - mid3(ax, l[i], u[i]);
-        double v = 0.5 * r * r;
-        v = 1 > v ? 1 : v;
-        v = 0.1 * v / den;
-        v = 1e3 < v ? 1e3 : v;
-        v = 1e-3 > v ? 1e-3 : v;
-        mu[i] = v;
-        double s = sqrt(v);
-        isq[i] = 1.0 / s;
-    }
-}
-
-// ---- infeasibility certificates (termination.c:97-216) -----------------------------------------
-// primal, stage 2: Atdy <- Dinv .* Atdy (n-part) ; oob partials (m-part)
-__global__ __launch_bounds__(256) void k_pinf_n(int n, int scaled, const double *__restrict__ Dinv, double *__restrict__ Atdy,
-                                                Ctrl *ctrl) {
-    __shared__ double sm[32];
-    double mx = 0.0;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        double v = Atdy[j];
-        if (scaled) { v = Dinv[j] * v; Atdy[j] = v; }
-        mx = absmax_acc(mx, v);
-    }
-    block_max_to(mx, &ctrl->nrm[N_B], sm);
-}
-__global__ __launch_bounds__(256) void k_pinf_m(int m, int scaled, const double *__restrict__ dy, const double *__restrict__ l,
-                                                const double *__restrict__ u, const double *__restrict__ E,
-                                                double *__restrict__ part) {
-    __shared__ double sm[32];
-    double s = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        const double e = scaled ? E[i] : 1.0, v = dy[i];
-        const double pos = v > 0 ? v : 0, neg = v < 0 ? v : 0;
-        s += (u[i] < e * QPDO_INFTY_D) ? u[i] * pos : 0;
-        s += (l[i] > -e * QPDO_INFTY_D) ? l[i] * neg : 0;
-    }
-    double t = block_sum(s, sm);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
-}
-__global__ void k_pinf_cert(int m, double cinv, const double *__restrict__ E, double *__restrict__ dy) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        double v = dy[i] * cinv;
-        dy[i] = E[i] * v;
-    }
-}
-// dual, stage 2: Adx <- Einv .* Adx, violation flag (termination.c:185-199)
-__global__ void k_dinf_m(int m, int scaled, double eps, const double *__restrict__ Einv, const double *__restrict__ E,
-                         const double *__restrict__ l, const double *__restrict__ u, double *__restrict__ Adx, Ctrl *ctrl) {
-    int viol = 0;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
-        double v = Adx[k];
-        const double e = scaled ? E[k] : 1.0;
-        if (scaled) { v = Einv[k] * v; Adx[k] = v; }
-        if ((u[k] < e * QPDO_INFTY_D && v >= eps) || (l[k] > -e * QPDO_INFTY_D && v <= -eps)) viol = 1;
-    }
-    if (viol) atomicOr(&ctrl->cnt[C_VIOL], 1);
-}
-// dual, stage 3: Qdx += (-sigma*tau) dx ; ||Qdx||inf ; partial q.dx
-__global__ __launch_bounds__(256) void k_dinf_n(int n, int prox, double st, const double *__restrict__ dx, const double *__restrict__ q,
-                                                double *__restrict__ Qdx, Ctrl *ctrl, double *__restrict__ part) {
-    __shared__ double sm[32];
-    double mx = 0.0, s = 0.0;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        double v = Qdx[j];
-        if (prox) { v = v + st * dx[j]; Qdx[j] = v; }
-        mx = absmax_acc(mx, v);
-        s += q[j] * dx[j];
-    }
-    block_max_to(mx, &ctrl->nrm[N_D], sm);
-    double t = block_sum(s, sm + 16);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
-}
-
-// ---- update_mu (iteration.c:127-168) -------------------------------------------------------------
-__global__ void k_update_mu(int m, double eps_abs, double theta, double delta, double mu_min, double isq_mu_min,
-                            const Ctrl *cin, const double *__restrict__ res_prim,
-                            const double *__restrict__ res_prim_old, double *__restrict__ mu, double *__restrict__ isq,
-                            double *__restrict__ at_scale, int *__restrict__ changed, Ctrl *ctrl) {
-    const double rpn = __longlong_as_double((long long)cin->nrm[N_A]);
-    int cnt = 0;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
-        const double rp = res_prim[k], arp = rp < 0 ? -rp : rp;
-        const double ro = res_prim_old[k], aro = ro < 0 ? -ro : ro;
-        const double thr = theta * aro;
-        int ch = 0;
-        if (arp > (eps_abs > thr ? eps_abs : thr)) {
-            const double ratio = delta * rpn / arp;
-            double mu_factor = 1.0 / (1.0 < ratio ? 1.0 : ratio);
-            const double mu_new = mu[k] / mu_factor;
-            if (mu_new >= mu_min) {
-                if (mu[k] != mu_new) ch = 1;
-                mu[k] = mu_new;
-                mu_factor = sqrt(mu_factor);
-                isq[k] = mu_factor * isq[k];
-                at_scale[k] = mu_factor;
-            } else {
-                if (mu[k] != mu_min) ch = 1;
-                mu[k] = mu_min;
-                at_scale[k] = isq_mu_min / isq[k];
-                isq[k] = isq_mu_min;
-            }
-        } else at_scale[k] = 1.0;
-        changed[k] = ch;
-        cnt += ch;
-    }
-    if (cnt) atomicAdd(&ctrl->cnt[C_MUCH], cnt);
-}
-// cholmod_interface.c:77-93 as a weight update: d_k += (isq_k * sqrt(1 - 1/s_k^2))^2 for every changed k
-__global__ void k_mu_changed_d(int m, const int *__restrict__ changed, const double *__restrict__ at_scale,
-                               const double *__restrict__ isq, double *__restrict__ d) {
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
-        if (changed[k]) {
-            const double s = at_scale[k];
-            const double r = sqrt(1 - 1 / (s * s));
-            const double col = isq[k] * r;
-            d[k] += col * col;
-        }
-    }
-}
-
-// ---- store_solution (termination.c:82-92) ---------------------------------------------------------
-__global__ void k_store_solution(int n, int m, int scaled, double cinv, const double *__restrict__ x, const double *__restrict__ D,
-                                 double *__restrict__ y, const double *__restrict__ E, double *__restrict__ sx,
-                                 double *__restrict__ sy) {
-    const int tot = n > m ? n : m;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += gridDim.x * blockDim.x) {
-        if (i < n) sx[i] = scaled ? x[i] * D[i] : x[i];
-        if (i < m) {
-            if (scaled) { const double v = y[i] * cinv; y[i] = v; sy[i] = v * E[i]; }
-            else sy[i] = y[i];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Jacobi-PCG on K = Q + sigma_f I + A' diag(d) A.  Every kernel leaves immediately once the
-// device-side `done` latch is set, so the host may launch iterations in batches and still stop
-// at exactly the iteration that met the tolerance.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pcg_init(int n, const double *__restrict__ b, const double *__restrict__ dg,
-                                                  double *__restrict__ x, double *__restrict__ r, double *__restrict__ z,
-                                                  double *__restrict__ p, double *__restrict__ p_rz, double *__restrict__ p_bb) {
-    __shared__ double sm[32];
-    double a = 0.0, c = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const double bi = b[i], zi = bi / dg[i];
-        x[i] = 0.0; r[i] = bi; z[i] = zi; p[i] = zi;
-        a += bi * zi; c += bi * bi;
-    }
-    double ta = block_sum(a, sm), tc = block_sum(c, sm + 16);
-    if (threadIdx.x == 0) { p_rz[blockIdx.x] = ta; p_bb[blockIdx.x] = tc; }
-}
-__global__ __launch_bounds__(256) void k_pcg_init2(const double *__restrict__ p_rz, int cnt_rz, const double *__restrict__ p_bb, int cnt, Ctrl *ctrl) {
-    __shared__ double sm[32];
-    double rz = reduce_partials(p_rz, cnt_rz, sm), bb = reduce_partials(p_bb, cnt, sm + 16);
-    if (threadIdx.x == 0) {
-        ctrl->val[V_RZ] = rz; ctrl->val[V_BNORM] = sqrt(bb);
-        ctrl->cnt[C_PCG_DONE] = (bb == 0.0) ? 1 : 0;
-        ctrl->cnt[C_PCG_IT] = 0;
-    }
-}
-// x += alpha p ; r -= alpha Kp ; z = r/diag ; partial r.z, r.r
-__global__ __launch_bounds__(256) void k_pcg_update(int n, const Ctrl *__restrict__ ctrl, const double *__restrict__ p_pKp, int pcnt,
-                                                    const double *__restrict__ p, const double *__restrict__ Kp,
-                                                    const double *__restrict__ dg, double *__restrict__ x, double *__restrict__ r,
-                                                    double *__restrict__ z, double *__restrict__ p_rz, double *__restrict__ p_rr) {
-    __shared__ double sm[32];
-    if (ctrl->cnt[C_PCG_DONE]) return;
-    const double pKp = reduce_partials(p_pKp, pcnt, sm);
-    const double alpha = ctrl->val[V_RZ] / pKp;
-    double a = 0.0, c = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        x[i] += alpha * p[i];
-        const double ri = r[i] - alpha * Kp[i];
-        r[i] = ri;
-        const double zi = ri / dg[i];
-        z[i] = zi;
-        a += ri * zi; c += ri * ri;
-    }
-    double ta = block_sum(a, sm), tc = block_sum(c, sm + 16);
-    if (threadIdx.x == 0) { p_rz[blockIdx.x] = ta; p_rr[blockIdx.x] = tc; }
-}
-// scalar step: convergence latch, beta, rz roll-over (single block)
-__global__ __launch_bounds__(256) void k_pcg_scalar(Ctrl *ctrl, const double *__restrict__ p_rz, int cnt_rz, const double *__restrict__ p_rr,
-                                                    int cnt, double tol) {
-    __shared__ double sm[32];
-    if (ctrl->cnt[C_PCG_DONE]) return;
-    const double rz2 = reduce_partials(p_rz, cnt_rz, sm), rr = reduce_partials(p_rr, cnt, sm + 16);
-    if (threadIdx.x == 0) {
-        ctrl->cnt[C_PCG_IT] += 1;
-        ctrl->val[V_RNORM] = sqrt(rr);
-        if (sqrt(rr) <= tol * ctrl->val[V_BNORM] || !(rr == rr)) ctrl->cnt[C_PCG_DONE] = 1;
-        ctrl->val[V_RR] = rz2 / ctrl->val[V_RZ];     // beta
-        ctrl->val[V_RZ] = rz2;
-    }
-}
-__global__ void k_pcg_p(int n, const Ctrl *__restrict__ ctrl, const double *__restrict__ z, double *__restrict__ p) {
-    if (ctrl->cnt[C_PCG_DONE]) return;
-    const double beta = ctrl->val[V_RR];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = z[i] + beta * p[i];
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Heavy-row deflation of the Jacobi preconditioner.  After a penalty update a handful of rows carry
-// weights d_i 1e4..1e6 times the median; they add isolated huge eigenvalues that cost Jacobi-PCG
-// thousands of iterations.  M = P + A_h' D_h A_h treats the (<= 64) heaviest rows exactly, with P the
-// Jacobi diagonal of the remainder:  M^-1 r = u - P^-1 A_h' S^-1 A_h u,  u = P^-1 r,
-// S = D_h^-1 + A_h P^-1 A_h'  (Woodbury; S is <= 64 x 64 and is inverted on the host once per pass).
-// The solution of K dx = rhs is unchanged; only the iteration count drops.
-// ------------------------------------------------------------------------------------------------
-static const int DEFL_MAX = 256;
-// hist[b] = #{ i : dmax/2^(b+1) < d_i <= dmax/2^b },  b = 0..31
-__global__ __launch_bounds__(256) void k_defl_hist(int m, const double *__restrict__ dw, const Ctrl *ctrl, int *__restrict__ hist) {
-    __shared__ int lh[32];
-    if (threadIdx.x < 32) lh[threadIdx.x] = 0;
-    __syncthreads();
-    const double dmax = __longlong_as_double((long long)ctrl->nrm[N_A]);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        const double v = dw[i];
-        if (v > 0.0) {
-            int b = 0; double t = dmax;
-            while (b < 31 && v <= t * 0.5) { t *= 0.5; b++; }
-            atomicAdd(&lh[b], 1);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 32 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
-}
-// ordered selection of rows with d_i > thr (single block): list, indicator flag, remainder weights
-__global__ __launch_bounds__(1024) void k_defl_select(int m, const double *__restrict__ dw, double thr, double *__restrict__ flag,
-                                                      double *__restrict__ dlight, int *__restrict__ list, int *__restrict__ count) {
-    __shared__ int sums[1024];
-    const int chunk = (m + 1023) / 1024;
-    const int beg = threadIdx.x * chunk, end = min(beg + chunk, m);
-    int c = 0;
-    for (int i = beg; i < end; i++) c += (dw[i] > thr);
-    sums[threadIdx.x] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; i++) { int t = sums[i]; sums[i] = run; run += t; } *count = run; }
-    __syncthreads();
-    int pos = sums[threadIdx.x];
-    for (int i = beg; i < end; i++) {
-        const bool h = dw[i] > thr;
-        flag[i] = h ? 1.0 : 0.0;
-        dlight[i] = h ? 0.0 : dw[i];
-        if (h) { if (pos < DEFL_MAX) list[pos] = i; pos++; }
-    }
-}
-// S(a,b) = [a==b]/d_a + sum_c A(h_a,c) A(h_b,c) / P_c ; one wave per pair, binary search in the sorted row b
-__global__ __launch_bounds__(64) void k_defl_S(int r, const int *__restrict__ list, const int *__restrict__ arp, const int *__restrict__ aci,
-                                               const double *__restrict__ aval, const double *__restrict__ P, const double *__restrict__ dw,
-                                               double *__restrict__ S) {
-    const int a = blockIdx.x, b = blockIdx.y;
-    if (a >= r || b > a) return;
-    const int ra = list[a], rb = list[b];
-    const int b0 = arp[rb], b1 = arp[rb + 1];
-    double sacc = 0.0;
-    for (int e = arp[ra] + threadIdx.x; e < arp[ra + 1]; e += 64) {
-        const int c = aci[e];
-        int lo = b0, hi = b1;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (aci[mid] < c) lo = mid + 1; else hi = mid; }
-        if (lo < b1 && aci[lo] == c) sacc += aval[e] * aval[lo] / P[c];
-    }
-    sacc = wave_sum(sacc);
-    if (threadIdx.x == 0) {
-        if (a == b) sacc += 1.0 / dw[ra];
-        S[a * DEFL_MAX + b] = sacc; S[b * DEFL_MAX + a] = sacc;
-    }
-}
-// v_a = A(h_a,:) u ; one wave per heavy row
-__global__ __launch_bounds__(64) void k_defl_v(const int *__restrict__ done, int r, const int *__restrict__ list, const int *__restrict__ arp,
-                                               const int *__restrict__ aci, const double *__restrict__ aval, const double *__restrict__ u,
-                                               double *__restrict__ v) {
-    if (done && *done) return;
-    const int a = blockIdx.x;
-    if (a >= r) return;
-    const int row = list[a];
-    double sacc = 0.0;
-    for (int e = arp[row] + threadIdx.x; e < arp[row + 1]; e += 64) sacc += aval[e] * u[aci[e]];
-    sacc = wave_sum(sacc);
-    if (threadIdx.x == 0) v[a] = sacc;
-}
-// w = S^-1 v (explicit inverse, row per lane), scattered to the m-vector th at the heavy rows
-__global__ __launch_bounds__(256) void k_defl_w(const int *__restrict__ done, int r, const double *__restrict__ Sinv, const double *__restrict__ v,
-                                               const int *__restrict__ list, double *__restrict__ th) {
-    if (done && *done) return;
-    const int a = threadIdx.x;
-    if (a >= r) return;
-    double sacc = 0.0;
-    for (int b = 0; b < r; b++) sacc += Sinv[b * DEFL_MAX + a] * v[b];      // S^-1 is symmetric: read it along the lanes
-    th[list[a]] = sacc;
-}
-struct EpiDeflZ {                          // z = u - (A_h' w) ./ P ; partial r.z
-    const double *P, *r; double *z, *p_rz; double acc = 0.0;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int j, double s) { const double zj = z[j] - s / P[j]; z[j] = zj; acc += r[j] * zj; }
-    __device__ void finish(double *sm) {
-        double t = block_sum(acc, sm);
-        if (threadIdx.x == 0) p_rz[blockIdx.x] = t;
-    }
-};
-__global__ void k_copy(int n, const double *__restrict__ a, double *__restrict__ b) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) b[i] = a[i];
-}
-
-// ------------------------------------------------------------------------------------------------
-// Exact linesearch (linesearch.c:74-158): stable LSD radix sort of the 2m breakpoints on the
-// 64-bit pattern of t (positive doubles order as unsigned integers; non-candidates carry a
-// sentinel key and sort last; ties keep index order like glibc's merge-sort qsort), then an
-// exclusive scan of the slope/intercept increments and a first-crossing search.
-// ------------------------------------------------------------------------------------------------
-static const int RS_ITEMS = 8;                       // keys per thread per tile
-static const int RS_TILE = BLK * RS_ITEMS;           // 2048
-
-__global__ __launch_bounds__(256) void k_rs_hist(const u64 *__restrict__ keys, int N, int shift, int nblocks, int *__restrict__ hist) {
-    __shared__ int lh[256];
-    lh[threadIdx.x] = 0;
-    __syncthreads();
-    const int base = blockIdx.x * RS_TILE;
-    for (int r = 0; r < RS_ITEMS; r++) {
-        const int i = base + r * BLK + threadIdx.x;
-        if (i < N) atomicAdd(&lh[(int)((keys[i] >> shift) & 255ull)], 1);
-    }
-    __syncthreads();
-    hist[threadIdx.x * nblocks + blockIdx.x] = lh[threadIdx.x];
-}
-// exclusive scan of hist (digit-major, length 256*nblocks) by one block
-__global__ __launch_bounds__(256) void k_rs_scan(int *__restrict__ hist, int total) {
-    __shared__ int sums[256];
-    const int chunk = (total + 255) / 256;
-    const int beg = threadIdx.x * chunk, end = min(beg + chunk, total);
-    int s = 0;
-    for (int i = beg; i < end; i++) s += hist[i];
-    sums[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; i++) { int t = sums[i]; sums[i] = run; run += t; } }
-    __syncthreads();
-    int run = sums[threadIdx.x];
-    for (int i = beg; i < end; i++) { int t = hist[i]; hist[i] = run; run += t; }
-}
-__global__ __launch_bounds__(256) void k_rs_scatter(const u64 *__restrict__ kin, const u32 *__restrict__ vin, u64 *__restrict__ kout,
-                                                    u32 *__restrict__ vout, int N, int shift, int nblocks,
-                                                    const int *__restrict__ hist) {
-    __shared__ int base[256];
-    __shared__ int cnt[4][256];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    base[tid] = hist[tid * nblocks + blockIdx.x];
-    const int tile = blockIdx.x * RS_TILE;
-    for (int r = 0; r < RS_ITEMS; r++) {
-        for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
-        __syncthreads();
-        const int i = tile + r * BLK + tid;
-        const bool valid = i < N;
-        u64 key = 0; u32 val = 0; int dig = 0;
-        if (valid) { key = kin[i]; val = vin[i]; dig = (int)((key >> shift) & 255ull); }
-        u64 peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const u64 bal = __ballot(valid && ((dig >> b) & 1));
-            peers &= ((dig >> b) & 1) ? bal : ~bal;
-        }
-        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
-        if (valid && rank == 0) cnt[wave][dig] = __popcll(peers);
-        __syncthreads();
-        if (valid) {
-            int off = base[dig] + rank;
-            for (int w = 0; w < wave; w++) off += cnt[w][dig];
-            kout[off] = key; vout[off] = val;
-        }
-        __syncthreads();
-        base[tid] += cnt[0][tid] + cnt[1][tid] + cnt[2][tid] + cnt[3][tid];
-        __syncthreads();
-    }
-}
-
-static const int LS_ITEMS = 4;
-static const int LS_TILE = BLK * LS_ITEMS;           // 1024 breakpoints per block
-// per-block exclusive scan of (da, db) over the sorted breakpoints; block totals to bt
-__global__ __launch_bounds__(256) void k_ls_scan1(const Ctrl *__restrict__ ctrl, const u32 *__restrict__ idx,
-                                                  const double *__restrict__ delta, const double *__restrict__ alpha,
-                                                  double *__restrict__ pa, double *__restrict__ pb, double *__restrict__ bt, int nblk) {
-    __shared__ double sa[256], sb[256];
-    const int nL = ctrl->cnt[C_NL];
-    const int base = blockIdx.x * LS_TILE + threadIdx.x * LS_ITEMS;
-    double da[LS_ITEMS], db[LS_ITEMS], ta = 0.0, tb = 0.0;
-#pragma unroll
-    for (int j = 0; j < LS_ITEMS; j++) {
-        const int k = base + j;
-        da[j] = 0.0; db[j] = 0.0;
-        if (k < nL) {
-            const u32 iz = idx[k];
-            const double dl = delta[iz], al = alpha[iz];
-            if (dl > 0) { da[j] = dl * dl; db[j] = -(dl * al); }      // linesearch.c:135-137
-            else        { da[j] = -(dl * dl); db[j] = dl * al; }      // linesearch.c:138-140
-        }
-        ta += da[j]; tb += db[j];
-    }
-    sa[threadIdx.x] = ta; sb[threadIdx.x] = tb;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double ra = 0.0, rb = 0.0;
-        for (int i = 0; i < 256; i++) { double t1 = sa[i], t2 = sb[i]; sa[i] = ra; sb[i] = rb; ra += t1; rb += t2; }
-        bt[blockIdx.x] = ra; bt[nblk + blockIdx.x] = rb;
-    }
-    __syncthreads();
-    double ra = sa[threadIdx.x], rb = sb[threadIdx.x];
-#pragma unroll
-    for (int j = 0; j < LS_ITEMS; j++) {
-        const int k = base + j;
-        if (k < nL) { pa[k] = ra; pb[k] = rb; }
-        ra += da[j]; rb += db[j];
-    }
-}
-// one block: a0, b0 from the partial sums (linesearch.c:19-25,119-120), exclusive scan of block totals
-__global__ __launch_bounds__(256) void k_ls_scan2(Ctrl *ctrl, const double *__restrict__ part, int pm, int pn, double *__restrict__ bt, int nblk) {
-    __shared__ double sm[32];
-    const double eta_m = reduce_partials(part + P_ETA_M * PGRID, pm, sm);
-    const double beta_m = reduce_partials(part + P_BETA_M * PGRID, pm, sm + 16);
-    const double ja = reduce_partials(part + P_A0 * PGRID, pm, sm);
-    const double jb = reduce_partials(part + P_B0 * PGRID, pm, sm + 16);
-    const double dxQdx = reduce_partials(part + P_DXQDX * PGRID, pn, sm);
-    const double dxdf = reduce_partials(part + P_DXDF * PGRID, pn, sm + 16);
-    if (threadIdx.x == 0) {
-        double eta = eta_m; eta += dxQdx; eta *= 0.5;
-        double beta = beta_m; beta += dxdf; beta *= 0.5;
-        ctrl->val[V_A0] = eta + ja;
-        ctrl->val[V_B0] = beta - jb;
-        ctrl->cnt[C_KSTAR] = 0x7fffffff;
-        const int nL = ctrl->cnt[C_NL];
-        const int used = (nL + LS_TILE - 1) / LS_TILE;
-        double ra = 0.0, rb = 0.0;
-        for (int i = 0; i < used; i++) {
-            double t1 = bt[i], t2 = bt[nblk + i];
-            bt[i] = ra; bt[nblk + i] = rb; ra += t1; rb += t2;
-        }
-        bt[2 * nblk] = ra; bt[2 * nblk + 1] = rb;     // grand totals
-    }
-}
-__global__ __launch_bounds__(256) void k_ls_search(Ctrl *ctrl, const u64 *__restrict__ key, const double *__restrict__ pa,
-                                                   const double *__restrict__ pb, const double *__restrict__ bt, int nblk) {
-    const int nL = ctrl->cnt[C_NL];
-    const double a0 = ctrl->val[V_A0], b0 = ctrl->val[V_B0];
-    int best = 0x7fffffff;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nL; k += gridDim.x * blockDim.x) {
-        const int blk = k / LS_TILE;
-        const double a = a0 + (bt[blk] + pa[k]), b = b0 + (bt[nblk + blk] + pb[k]);
-        const double t = __longlong_as_double((long long)key[k]);
-        if (b + a * t > 0) { best = k; break; }       // ascending k per thread: first hit is its minimum
-    }
-    if (best != 0x7fffffff) atomicMin(&ctrl->cnt[C_KSTAR], best);
-}
-__global__ void k_ls_final(Ctrl *ctrl, const double *__restrict__ pa, const double *__restrict__ pb, const double *__restrict__ bt, int nblk) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int nL = ctrl->cnt[C_NL];
-    const double a0 = ctrl->val[V_A0], b0 = ctrl->val[V_B0];
-    const int ks = ctrl->cnt[C_KSTAR];
-    double a, b;
-    if (nL == 0) { a = a0; b = b0; }
-    else if (ks >= nL) { a = a0 + bt[2 * nblk]; b = b0 + bt[2 * nblk + 1]; }
-    else { const int blk = ks / LS_TILE; a = a0 + (bt[blk] + pa[ks]); b = b0 + (bt[nblk + blk] + pb[ks]); }
-    ctrl->val[V_TAU] = -b / a;
-}
-// standalone prep for the linesearch parity entry point (caller supplies eta, beta, delta, alpha)
-__global__ __launch_bounds__(256) void k_ls_prep_raw(int M2, const double *__restrict__ delta, const double *__restrict__ alpha,
-                                                     u64 *__restrict__ key, u32 *__restrict__ idx, double *__restrict__ p_a0,
-                                                     double *__restrict__ p_b0, Ctrl *ctrl) {
-    __shared__ double sm[32];
-    double a0 = 0.0, b0 = 0.0; int nL = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M2; i += gridDim.x * blockDim.x) {
-        const double dl = delta[i], al = alpha[i], t = al / dl;
-        const bool L = t > 0, P = dl > 0;
-        key[i] = L ? (u64)__double_as_longlong(t) : KEY_SENTINEL;
-        idx[i] = (u32)i;
-        if (L) nL++;
-        if (L != P) { a0 += dl * dl; b0 += dl * al; }
-    }
-    double t3 = block_sum(a0, sm), t4 = block_sum(b0, sm + 16);
-    int tn = block_sum_int(nL, (int *)sm);
-    if (threadIdx.x == 0) { p_a0[blockIdx.x] = t3; p_b0[blockIdx.x] = t4; if (tn) atomicAdd(&ctrl->cnt[C_NL], tn); }
-}
-__global__ void k_set_partial(double *p, double v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
-__global__ void k_ctrl_set_int(Ctrl *c, int slot, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) c->cnt[slot] = v; }
-__global__ void k_ctrl_set_nrm0(Ctrl *c, int slot) { if (threadIdx.x == 0 && blockIdx.x == 0) c->nrm[slot] = 0ull; }
-
-
-// ================================================================================================
-// Dense direct solver for K = Q + sigma_f I + A' diag(d) A  (reference N2/N4: cholmod_interface.c:8-52,
-// 98-102).  With CHOLMOD's natural ordering and percent-level fill the normal-equations term is
-// structurally dense, i.e. the supernodal factorization degenerates to ONE dense front of order n;
-// this is that front: blocked right-looking LDL' (no pivoting, as CHOLMOD_LDLt on an SPD matrix) whose
-// trailing update runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).  Used when n <= dense_max_n.
-// Storage: column-major lower triangle K[i + j*ld], ld = n rounded up to 64; the padding carries an
-// identity so every block is full.  W (ld x 64) holds the scaled panel L*D of the current step.
-// ================================================================================================
-static const int DNB = 64;
-typedef double dvec4 __attribute__((ext_vector_type(4)));
-
-// one wave per column j: acc (LDS, n doubles) gathers Q(:,j) and sum_r d_r a_rj a_r(:) for rows >= j.
-// Sequential over r inside the wave, so the summation order is fixed (reproducible).
-__global__ __launch_bounds__(64) void k_dense_assemble(int n, int ld, const int *__restrict__ qrp, const int *__restrict__ qci,
-                                                       const double *__restrict__ qval, const int *__restrict__ trp,
-                                                       const int *__restrict__ tci, const double *__restrict__ tval,
-                                                       const int *__restrict__ arp, const int *__restrict__ aci,
-                                                       const double *__restrict__ aval, const double *__restrict__ dw,
-                                                       double sigma_f, double *__restrict__ K) {
-    extern __shared__ __attribute__((aligned(16))) double acc[];
-    const int lane = threadIdx.x;
-    for (int j = blockIdx.x; j < ld; j += gridDim.x) {
-        double *col = K + (size_t)j * ld;
-        if (j >= n) {                                  // identity padding
-            for (int i = j + lane; i < ld; i += 64) col[i] = (i == j) ? 1.0 : 0.0;
-            continue;
-        }
-        for (int i = j + lane; i < n; i += 64) acc[i] = 0.0;
-        __syncthreads();
-        for (int k = qrp[j] + lane; k < qrp[j + 1]; k += 64) { const int i = qci[k]; if (i >= j) acc[i] += qval[k]; }
-        __syncthreads();
-        for (int t = trp[j]; t < trp[j + 1]; t++) {
-            const int r = tci[t];
-            const double wgt = dw[r];
-            if (wgt == 0.0) continue;
-            const double w = wgt * tval[t];
-            for (int e = arp[r] + lane; e < arp[r + 1]; e += 64) { const int i = aci[e]; if (i >= j) acc[i] += w * aval[e]; }
-            __syncthreads();                           // one wave: orders the LDS read-modify-writes of consecutive rows
-        }
-        __syncthreads();
-        if (lane == 0) acc[j] += sigma_f;
-        __syncthreads();
-        for (int i = j + lane; i < ld; i += 64) col[i] = (i < n) ? acc[i] : 0.0;
-    }
-}
-// 64x64x64 product on the matrix cores for one workgroup of 4 waves: wave w owns the 32x32 quadrant
-// (w>>1, w&1) as 2x2 tiles of v_mfma_f64_16x16x4_f64; As/Bs are [k][row] / [k][col] LDS images with a row
-// stride of 80 doubles (the two k-rows a half-wave reads land on disjoint banks).
-// A/B lane map: lane l holds A[l&15][k = l>>4], B[k = l>>4][l&15]; C/D: row = (l>>4) + 4*reg, col = l&15.
-__device__ __forceinline__ void mfma_64x64x64(const double (*As)[80], const double (*Bs)[80], dvec4 acc[2][2], int wr, int wc, int li, int lk) {
-#pragma unroll 4
-    for (int k0 = 0; k0 < DNB; k0 += 4) {
-        const double a0 = As[k0 + lk][wr + li], a1 = As[k0 + lk][wr + 16 + li];
-        const double b0 = Bs[k0 + lk][wc + li], b1 = Bs[k0 + lk][wc + 16 + li];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-    }
-}
-// LDL' of the 64x64 diagonal block kb; writes unit-lower L back, D to Dg, the inverse of L
-// (column-major: Li[c*64 + r] = (L^-1)[r][c]) for the panel solve and the forward solves, and its transpose
-// (LiT[r*64 + c]) for the backward solves.
-// Two waves: lane i of wave 0 keeps row i of the block, lane i of wave 1 column i of the running inverse,
-// both as 64 registers (fully unrolled: every register index is a constant).  Step j: wave 0 publishes column j
-// through LDS, every lane reads it back as broadcasts and applies  r_c -= (r_j / d_j) v_c  for c > j -- for wave 0
-// that is a_ic -= l_ij v_c, for wave 1 the row operation X(c,i) -= l_cj X(j,i) of Gauss-Jordan on the identity.
-// A step costs one two-wave barrier and one LDS round trip (28 us per block; a 1024-thread version with a
-// 16-wave barrier per step took 61 us).  The two roles differ only by selects, never by branches around the
-// register array (divergent copies of it spill).
-__global__ __launch_bounds__(128) void k_ldl_diag(double *__restrict__ K, int ld, int kb, double *__restrict__ Dg, double *__restrict__ Linv,
-                                                   double *__restrict__ LinvT) {
-    __shared__ double colb[2][DNB];
-    __shared__ double Ts[DNB][DNB + 1];
-    const int i = threadIdx.x & 63;
-    const bool is_a = threadIdx.x < 64;
-    const size_t base = (size_t)kb * DNB + (size_t)kb * DNB * ld;
-    double r[DNB];
-#pragma unroll
-    for (int c = 0; c < DNB; c++) { const double v = K[base + i + (size_t)c * ld]; r[c] = is_a ? v : ((c == i) ? 1.0 : 0.0); }
-#pragma unroll
-    for (int j = 0; j < DNB; j++) {
-        double *cb = colb[j & 1];
-        if (is_a) cb[i] = r[j];                                    // v_i = A(i,j), rows i >= j are current
-        __syncthreads();
-        const double inv = 1.0 / cb[j];
-        const double sj = r[j] * inv;                              // l_ij (wave 0) or X(j,i)/d_j (wave 1)
-#pragma unroll
-        for (int c = j + 1; c < DNB; c++) r[c] = fma(-sj, cb[c], r[c]);
-        r[j] = (is_a && i > j) ? sj : r[j];                        // lane j keeps d_j in r[j]
-    }
-#pragma unroll
-    for (int c = 0; c < DNB; c++) {
-        if (is_a && i > c) K[base + i + (size_t)c * ld] = r[c];
-        if (is_a && i == c) Dg[kb * DNB + c] = r[c];
-        if (!is_a) Ts[i][c] = r[c];
-    }
-    __syncthreads();
-    double *o = Linv + (size_t)kb * DNB * DNB, *ot = LinvT + (size_t)kb * DNB * DNB;
-    for (int e = threadIdx.x; e < DNB * DNB; e += 128) {
-        const int c = e >> 6, q = e & 63;
-        o[(size_t)c * DNB + q] = Ts[c][q];                         // (L^-1)[q][c]
-        ot[(size_t)c * DNB + q] = Ts[q][c];                        // transpose image: LiT[c*64 + q] = (L^-1)[c][q]
-    }
-}
-// panel below the diagonal block on the matrix cores: X = A L_kk^-T  =>  W = X (= L D), L = X / D.  L is also written
-// transposed into the upper triangle of K so that the backward solve reads contiguous columns.
-// One workgroup per 64-row tile.
-__global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ K, int ld, int kb, int wcol, const double *__restrict__ Dg,
-                                                   const double *__restrict__ Linv, double *__restrict__ W) {
-    __shared__ double As[DNB][80];
-    __shared__ double Bs[DNB][80];
-    const int tid = threadIdx.x;
-    const int ti = kb + 1 + blockIdx.x;
-    const double *Li = Linv + (size_t)kb * DNB * DNB;
-    for (int idx = tid; idx < DNB * DNB; idx += 256) {
-        const int r = idx % DNB, k = idx / DNB;
-        As[k][r] = K[(size_t)ti * DNB + r + ((size_t)kb * DNB + k) * ld];      // A[row r][k]
-        Bs[k][r] = Li[(size_t)k * DNB + r];                                     // B[k][col r] = (L^-1)[r][k]
-    }
-    __syncthreads();
-    const int wave = tid >> 6, l = tid & 63;
-    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-    const int li = l & 15, lk = l >> 4;
-    dvec4 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int q = 0; q < 2; q++) acc[m][q] = (dvec4){0.0, 0.0, 0.0, 0.0};
-    mfma_64x64x64(As, Bs, acc, wr, wc, li, lk);
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const int row = wr + m * 16 + lk + 4 * v, col = wc + q * 16 + li;
-                const double x = acc[m][q][v];
-                W[(size_t)ti * DNB + row + ((size_t)wcol * DNB + col) * ld] = x;
-                const double lv = x / Dg[kb * DNB + col];
-                K[(size_t)ti * DNB + row + ((size_t)kb * DNB + col) * ld] = lv;
-                K[(size_t)kb * DNB + col + ((size_t)ti * DNB + row) * ld] = lv;         // L' in the (otherwise unused) upper triangle
-            }
-}
-// update on the matrix cores: C(ti,tj) -= sum_{q<nkb} W(ti, wcol0+q) * L(tj, kb0+q)'  for tj in [tj_lo, tj_hi), ti >= tj.
-// nkb = 1 updates the rest of the current 256-wide outer panel, nkb = 4 the trailing matrix (one read-modify-write
-// of C per 256 eliminated columns instead of per 64).  Software pipelined: the k dimension is cut into 32-deep
-// chunks held in double-buffered LDS tiles; the global loads of chunk c+1 are in flight while the MFMAs of chunk c
-// run (one barrier per chunk; 16-deep chunks: 40 KB LDS => four workgroups per CU, 32-deep: 80 KB => two).
-template <int SY_KC>
-__global__ __launch_bounds__(256) void k_ldl_syrk(double *__restrict__ K, int ld, const double *__restrict__ W, int kb0, int nkb, int wcol0,
-                                                  int tj_lo, int tj_hi) {
-    const int ti = tj_lo + blockIdx.x, tj = tj_lo + blockIdx.y;
-    if (tj >= tj_hi || tj > ti) return;
-    // one LDS array: A tiles [buf][k][row] at S + buf*T, B tiles at S + (2+buf)*T, T = SY_KC*80 (row stride 80 doubles: the
-    // two k-rows of a half-wave hit disjoint banks); reused as the [col][row] image of the C tile in the epilogue
-    constexpr int T = SY_KC * 80;
-    constexpr int SZ = (4 * T > DNB * (DNB + 1)) ? 4 * T : DNB * (DNB + 1);
-    __shared__ double S[SZ];
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, l = tid & 63;
-    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-    const int li = l & 15, lk = l >> 4;
-    const int lr = tid & 63, lk0 = tid >> 6;                      // this thread stages rows lr, k = lk0 + 4 e
-    const int nch = nkb * (DNB / SY_KC);
-    const double *Wp = W + (size_t)ti * DNB + lr, *Kp = K + (size_t)tj * DNB + lr;
-    double ra[SY_KC / 4], rb[SY_KC / 4];
-    auto gload = [&](int ch) {
-        const int q = ch / (DNB / SY_KC), h = ch % (DNB / SY_KC);
-        const size_t wc0 = ((size_t)(wcol0 + q) * DNB + (size_t)h * SY_KC) * ld, kc0 = ((size_t)(kb0 + q) * DNB + (size_t)h * SY_KC) * ld;
-#pragma unroll
-        for (int e = 0; e < SY_KC / 4; e++) { const size_t ko = (size_t)(lk0 + 4 * e) * ld; ra[e] = Wp[wc0 + ko]; rb[e] = Kp[kc0 + ko]; }
-    };
-    auto lstore = [&](int buf) {
-        double *A = S + buf * T, *B = S + (2 + buf) * T;
-#pragma unroll
-        for (int e = 0; e < SY_KC / 4; e++) { A[(lk0 + 4 * e) * 80 + lr] = ra[e]; B[(lk0 + 4 * e) * 80 + lr] = rb[e]; }
-    };
-    dvec4 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int q = 0; q < 2; q++) acc[m][q] = (dvec4){0.0, 0.0, 0.0, 0.0};
-    gload(0); lstore(0);
-    __syncthreads();
-    for (int ch = 0; ch < nch; ch++) {
-        const int buf = ch & 1;
-        const double *A = S + buf * T, *B = S + (2 + buf) * T;
-        if (ch + 1 < nch) gload(ch + 1);                         // in flight during the MFMAs below
-#pragma unroll
-        for (int k0 = 0; k0 < SY_KC; k0 += 4) {
-            const double a0 = A[(k0 + lk) * 80 + wr + li], a1 = A[(k0 + lk) * 80 + wr + 16 + li];
-            const double b0 = B[(k0 + lk) * 80 + wc + li], b1 = B[(k0 + lk) * 80 + wc + 16 + li];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (ch + 1 < nch) lstore(buf ^ 1);
-        __syncthreads();
-    }
-    // C -= acc, coalesced: the accumulators (4 rows x 16 columns per wave instruction) go through LDS as a [col][row]
-    // image so that the global read-modify-write runs along the contiguous rows
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) S[(wc + q * 16 + li) * (DNB + 1) + wr + m * 16 + lk + 4 * v] = acc[m][q][v];
-    __syncthreads();
-    double *Cp = K + (size_t)ti * DNB + lr + (size_t)tj * DNB * ld;
-#pragma unroll 4
-    for (int e = 0; e < DNB / 4; e++) {
-        const int col = lk0 + 4 * e;
-        double *cp = Cp + (size_t)col * ld;
-        *cp = *cp - S[col * (DNB + 1) + lr];
-    }
-}
-// forward step kb: z_k = L_kk^-1 x_k (matrix-vector with the stored inverse: no serial chain), wave 0 publishes
-// it, then wave b updates the 64 rows of block kb+1+b:  x_i -= L(i, kb) z_k.
-__global__ __launch_bounds__(64) void k_ldl_fwd(const double *__restrict__ K, int ld, int kb, const double *__restrict__ Linv,
-                                                double *__restrict__ x, double *__restrict__ z) {
-    __shared__ double xs[DNB], zs[DNB];
-    const int l = threadIdx.x;
-    xs[l] = x[kb * DNB + l];
-    __syncthreads();
-    const double *Li = Linv + (size_t)kb * DNB * DNB;
-    double v = 0.0;
-    for (int c = 0; c < DNB; c++) v += Li[(size_t)c * DNB + l] * xs[c];
-    zs[l] = v;
-    if (blockIdx.x == 0) z[kb * DNB + l] = v;
-    __syncthreads();
-    const int r = (kb + 1 + blockIdx.x) * DNB + l;
-    if (r >= ld) return;
-    const double *row = K + r + (size_t)kb * DNB * ld;
-    double sacc = x[r];
-    for (int c = 0; c < DNB; c++) sacc -= row[(size_t)c * ld] * zs[c];
-    x[r] = sacc;
-}
-// backward step kb: x_k = L_kk^-T y_k, publish, then wave j (< kb) updates y_j -= L(kb, j)' x_k through an LDS
-// transpose of the 64x64 tile.
-__global__ __launch_bounds__(64) void k_ldl_bwd(const double *__restrict__ K, int ld, int kb, const double *__restrict__ Linv,
-                                                double *__restrict__ y, double *__restrict__ xout) {
-    __shared__ double xs[DNB], ys[DNB];
-    __shared__ double tile[DNB][DNB + 1];
-    const int l = threadIdx.x;
-    ys[l] = y[kb * DNB + l];
-    const double *Li = Linv + (size_t)kb * DNB * DNB;
-    for (int c = 0; c < DNB; c++) tile[l][c] = Li[(size_t)c * DNB + l];        // tile[r][c] = (L^-1)[r][c]
-    __syncthreads();
-    double v = 0.0;
-    for (int r = 0; r < DNB; r++) v += tile[r][l] * ys[r];                      // (L^-T y)_l = sum_r (L^-1)[r][l] y_r
-    xs[l] = v;
-    if (blockIdx.x == 0) xout[kb * DNB + l] = v;
-    __syncthreads();
-    const int j = blockIdx.x;                            // 0 .. kb-1
-    if (kb == 0 || j >= kb) return;
-    for (int c = 0; c < DNB; c++) tile[l][c] = K[(size_t)kb * DNB + l + ((size_t)j * DNB + c) * ld];   // rows contiguous across lanes
-    __syncthreads();
-    double sacc = y[j * DNB + l];
-    for (int r = 0; r < DNB; r++) sacc -= tile[r][l] * xs[r];
-    y[j * DNB + l] = sacc;
-}
-// ---- triangular solves as ONE launch per direction ------------------------------------------------------
-// Workgroup b owns block row b.  Forward: x_b - sum_{k<b} L(b,k) z_k, then z_b = L_bb^-1 (.), published to z; the
-// consumers poll z itself (pre-filled with a signalling-NaN pattern no arithmetic produces) with device-scope
-// loads, so one cross-XCD round trip separates consecutive steps instead of a kernel launch (157 dependent
-// launches of ~11.5 us at n = 1e4).  Backward is the same kernel on the transposed tiles the panel kernel left in
-// the upper triangle, with the block order reversed.  Workgroup b waits only on workgroups dispatched before it,
-// so the grid drains for any dispatch width; a bounded spin turns a lost producer into NaNs + C_CHAIN_ERR.
-static const unsigned long long CH_SENT = 0x7FF4DEADBEEF0001ULL;
-static const int CH_SPIN_MAX = 1 << 22;
-__device__ __forceinline__ double lane_bcast(double v, int lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane); hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
-__global__ void k_fill_sentinel(int n, double *__restrict__ a, double *__restrict__ b) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        reinterpret_cast<unsigned long long *>(a)[i] = CH_SENT; reinterpret_cast<unsigned long long *>(b)[i] = CH_SENT;
-    }
-}
-template <bool FWD>
-__global__ __launch_bounds__(256) void k_ldl_chain(const double *__restrict__ K, int ld, int nb, const double *__restrict__ Li,
-                                                   const double *__restrict__ Dg, const double *__restrict__ rhs, double *pub,
-                                                   double *__restrict__ yout, Ctrl *ctrl) {
-    __shared__ double part[4][DNB];
-    __shared__ double tot[DNB];
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int ndep = blockIdx.x;                                    // blocks this one waits for
-    const int b = FWD ? (int)blockIdx.x : nb - 1 - (int)blockIdx.x;
-    double li[16], cur[16], nxt[16];
-    const double *Lb = Li + (size_t)b * DNB * DNB + (size_t)(w * 16) * DNB + l;
-#pragma unroll
-    for (int q = 0; q < 16; q++) li[q] = Lb[(size_t)q * DNB];
-    const double *Kb = K + (size_t)b * DNB + l + (size_t)(w * 16) * ld;      // tile (b,k): + k*64*ld, element (l, w*16+q): + q*ld
-    auto kof = [&](int j) { return FWD ? j : nb - 1 - j; };
-    if (ndep > 0) {
-        const double *t = Kb + (size_t)kof(0) * DNB * ld;
-#pragma unroll
-        for (int q = 0; q < 16; q++) cur[q] = t[(size_t)q * ld];
-    }
-    double acc = 0.0;
-    bool lost = false;
-    for (int j = 0; j < ndep; j++) {
-        if (j + 1 < ndep) {
-            const double *t = Kb + (size_t)kof(j + 1) * DNB * ld;
-#pragma unroll
-            for (int q = 0; q < 16; q++) nxt[q] = t[(size_t)q * ld];
-        }
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(pub) + (size_t)kof(j) * DNB + w * 16 + (l & 15);
-        unsigned long long bits = CH_SENT;
-        int spins = 0;
-        for (;;) {
-            if (l < 16) bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(l >= 16 || bits != CH_SENT)) break;
-            if (++spins > CH_SPIN_MAX) { lost = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        const double v = lost ? __longlong_as_double(0x7FF8000000000000LL) : __longlong_as_double((long long)bits);
-#pragma unroll
-        for (int q = 0; q < 16; q++) acc += cur[q] * lane_bcast(v, q);
-#pragma unroll
-        for (int q = 0; q < 16; q++) cur[q] = nxt[q];
-    }
-    part[w][l] = acc;
-    __syncthreads();
-    if (w == 0) tot[l] = rhs[(size_t)b * DNB + l] - ((part[0][l] + part[1][l]) + (part[2][l] + part[3][l]));
-    __syncthreads();
-    double s = 0.0;
-#pragma unroll
-    for (int q = 0; q < 16; q++) s += li[q] * tot[w * 16 + q];
-    part[w][l] = s;                                                 // the first use of part ended before the barrier above
-    __syncthreads();
-    if (w == 0) {
-        double r = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
-        unsigned long long rb = (unsigned long long)__double_as_longlong(r);
-        if (rb == CH_SENT) rb = 0x7FF8000000000000ULL;
-        if (FWD) yout[(size_t)b * DNB + l] = r / Dg[(size_t)b * DNB + l];
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(pub) + (size_t)b * DNB + l, rb, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (lost && tid == 0) atomicOr(&ctrl->cnt[C_CHAIN_ERR], 1);
-}
-
-// ---- multi right-hand-side block solves (MFMA) and the low-rank factor update -------------------------
-// The reference keeps its factor current with rank-<=100 LDL' up/downdates when few rows enter or leave
-// (cholmod_interface.c:57-93, newton.c:21-30).  Here the factor K0 = L D L' of the last full factorization
-// is kept and the change K = K0 + U' W U (U = the rows of A whose weight d_i moved since then, W = diag(d - d_fact))
-// is applied in the solve:  K^-1 r = z0 - Z (I + W G)^-1 W U z0,  z0 = K0^-1 r,  Z = K0^-1 U',  G = U Z.
-// Z gains one column per new row (a multi right-hand-side solve with MFMA tiles), G one row and column;
-// the (<= WB_MAX)^2 system is solved in LDS.  Same linear system as the reference's updated factor.
-static const int WB_MAX = 128;
-static const double WB_MIN_PIVOT = 1e-6;      // smallest |pivot| of I + W G accepted (refinement recovers a few digits, not a singular downdate)
-// forward step kb for nr (multiple of 16) right-hand sides X (ld x nr): Z_kb = L_kk^-1 X_kb, X_i -= L(i,kb) Z_kb
-__global__ __launch_bounds__(256) void k_ldl_fwd_mr(const double *__restrict__ K, int ld, int kb, const double *__restrict__ Linv,
-                                                    double *__restrict__ X, double *__restrict__ Zo, int nr, int nb) {
-    extern __shared__ double smr[];
-    double *As = smr;                    // [k][row], stride 80
-    double *Bs = smr + DNB * 80;         // [col][k], stride 68 (X_kb, then Z_kb)
-    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
-    const int r64 = tid & 63, q4 = tid >> 6;
-    const int ng = nr >> 4;
-    const int g0 = wave, g1 = wave + 4;
-    const bool v0 = g0 < ng, v1 = g1 < ng;
-    const double *Li = Linv + (size_t)kb * DNB * DNB;
-    for (int e = 0; e < DNB / 4; e++) { const int k = q4 + 4 * e; As[k * 80 + r64] = Li[(size_t)k * DNB + r64]; }
-    for (int c = q4; c < nr; c += 4) Bs[c * 68 + r64] = X[(size_t)kb * DNB + r64 + (size_t)c * ld];
-    __syncthreads();
-    dvec4 acc[4][2];
-    auto zero = [&]() {
-#pragma unroll
-        for (int m = 0; m < 4; m++) { acc[m][0] = (dvec4){0.0, 0.0, 0.0, 0.0}; acc[m][1] = (dvec4){0.0, 0.0, 0.0, 0.0}; }
-    };
-    auto gemm = [&]() {
-#pragma unroll 4
-        for (int k0 = 0; k0 < DNB; k0 += 4) {
-            double a[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) a[m] = As[(k0 + lk) * 80 + m * 16 + li];
-            if (v0) {
-                const double b = Bs[(g0 * 16 + li) * 68 + k0 + lk];
-#pragma unroll
-                for (int m = 0; m < 4; m++) acc[m][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b, acc[m][0], 0, 0, 0);
-            }
-            if (v1) {
-                const double b = Bs[(g1 * 16 + li) * 68 + k0 + lk];
-#pragma unroll
-                for (int m = 0; m < 4; m++) acc[m][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b, acc[m][1], 0, 0, 0);
-            }
-        }
-    };
-    zero(); gemm();
-    __syncthreads();
-    // Z_kb replaces X_kb in LDS
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            if (v0) Bs[(g0 * 16 + li) * 68 + m * 16 + lk + 4 * v] = acc[m][0][v];
-            if (v1) Bs[(g1 * 16 + li) * 68 + m * 16 + lk + 4 * v] = acc[m][1][v];
-        }
-    __syncthreads();
-    if (blockIdx.x == 0)
-        for (int c = q4; c < nr; c += 4) Zo[(size_t)kb * DNB + r64 + (size_t)c * ld] = Bs[c * 68 + r64];
-    const int ib = kb + 1 + blockIdx.x;
-    if (ib >= nb) return;
-    for (int e = 0; e < DNB / 4; e++) { const int k = q4 + 4 * e; As[k * 80 + r64] = K[(size_t)ib * DNB + r64 + ((size_t)kb * DNB + k) * ld]; }
-    __syncthreads();
-    zero(); gemm();
-    __syncthreads();
-    double *Cs = smr;                    // [col][row], stride 65, over As and Bs
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            if (v0) Cs[(g0 * 16 + li) * 65 + m * 16 + lk + 4 * v] = acc[m][0][v];
-            if (v1) Cs[(g1 * 16 + li) * 65 + m * 16 + lk + 4 * v] = acc[m][1][v];
-        }
-    __syncthreads();
-    for (int c = q4; c < nr; c += 4) { double *xp = X + (size_t)ib * DNB + r64 + (size_t)c * ld; *xp = *xp - Cs[c * 65 + r64]; }
-}
-// backward step kb: X_kb = L_kk^-T Y_kb, Y_j -= L(kb,j)' X_kb for j < kb
-__global__ __launch_bounds__(256) void k_ldl_bwd_mr(const double *__restrict__ K, int ld, int kb, const double *__restrict__ Linv,
-                                                    double *__restrict__ Y, double *__restrict__ Xo, int nr) {
-    extern __shared__ double smr[];
-    double *As = smr;                    // [row = column c of the tile][k = row r of the tile], stride 68
-    double *Bs = smr + DNB * 68;         // [col][k], stride 68
-    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
-    const int r64 = tid & 63, q4 = tid >> 6;
-    const int ng = nr >> 4;
-    const int g0 = wave, g1 = wave + 4;
-    const bool v0 = g0 < ng, v1 = g1 < ng;
-    const double *Li = Linv + (size_t)kb * DNB * DNB;
-    for (int e = 0; e < DNB / 4; e++) { const int c = q4 + 4 * e; As[c * 68 + r64] = Li[(size_t)c * DNB + r64]; }
-    for (int c = q4; c < nr; c += 4) Bs[c * 68 + r64] = Y[(size_t)kb * DNB + r64 + (size_t)c * ld];
-    __syncthreads();
-    dvec4 acc[4][2];
-    auto zero = [&]() {
-#pragma unroll
-        for (int m = 0; m < 4; m++) { acc[m][0] = (dvec4){0.0, 0.0, 0.0, 0.0}; acc[m][1] = (dvec4){0.0, 0.0, 0.0, 0.0}; }
-    };
-    auto gemm = [&]() {
-#pragma unroll 4
-        for (int k0 = 0; k0 < DNB; k0 += 4) {
-            double a[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) a[m] = As[(m * 16 + li) * 68 + k0 + lk];
-            if (v0) {
-                const double b = Bs[(g0 * 16 + li) * 68 + k0 + lk];
-#pragma unroll
-                for (int m = 0; m < 4; m++) acc[m][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b, acc[m][0], 0, 0, 0);
-            }
-            if (v1) {
-                const double b = Bs[(g1 * 16 + li) * 68 + k0 + lk];
-#pragma unroll
-                for (int m = 0; m < 4; m++) acc[m][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b, acc[m][1], 0, 0, 0);
-            }
-        }
-    };
-    zero(); gemm();
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            if (v0) Bs[(g0 * 16 + li) * 68 + m * 16 + lk + 4 * v] = acc[m][0][v];
-            if (v1) Bs[(g1 * 16 + li) * 68 + m * 16 + lk + 4 * v] = acc[m][1][v];
-        }
-    __syncthreads();
-    if (blockIdx.x == 0)
-        for (int c = q4; c < nr; c += 4) Xo[(size_t)kb * DNB + r64 + (size_t)c * ld] = Bs[c * 68 + r64];
-    const int j = blockIdx.x;
-    if (kb == 0 || j >= kb) return;
-    for (int e = 0; e < DNB / 4; e++) { const int c = q4 + 4 * e; As[c * 68 + r64] = K[(size_t)kb * DNB + r64 + ((size_t)j * DNB + c) * ld]; }
-    __syncthreads();
-    zero(); gemm();
-    __syncthreads();
-    double *Cs = smr;
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            if (v0) Cs[(g0 * 16 + li) * 65 + m * 16 + lk + 4 * v] = acc[m][0][v];
-            if (v1) Cs[(g1 * 16 + li) * 65 + m * 16 + lk + 4 * v] = acc[m][1][v];
-        }
-    __syncthreads();
-    for (int c = q4; c < nr; c += 4) { double *yp = Y + (size_t)j * DNB + r64 + (size_t)c * ld; *yp = *yp - Cs[c * 65 + r64]; }
-}
-__global__ void k_scale_d_mr(int ld, int nr, const double *__restrict__ Dg, double *__restrict__ Z) {
-    const size_t tot = (size_t)ld * nr;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) Z[i] = Z[i] / Dg[i % ld];
-}
-// rows whose weight moved since the factorization and that hold no slot yet get the next slots, in row order
-__global__ __launch_bounds__(1024) void k_wb_select(int m, const double *__restrict__ dw, const double *__restrict__ dfact, int *__restrict__ slot,
-                                                    int *__restrict__ rows, int k_old, int *__restrict__ cnt) {
-    __shared__ int sums[1024];
-    const int chunk = (m + 1023) / 1024;
-    const int beg = threadIdx.x * chunk, end = min(beg + chunk, m);
-    int c = 0;
-    for (int i = beg; i < end; i++) c += (dw[i] != dfact[i] && slot[i] < 0);
-    sums[threadIdx.x] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; i++) { int t = sums[i]; sums[i] = run; run += t; } cnt[0] = k_old + run; }
-    __syncthreads();
-    int pos = k_old + sums[threadIdx.x];
-    for (int i = beg; i < end; i++)
-        if (dw[i] != dfact[i] && slot[i] < 0) { if (pos < WB_MAX) { rows[pos] = i; slot[i] = pos; } pos++; }
-}
-// right-hand side columns: X(:, k_old + b) = row rows[k_old + b] of A as a dense vector (zero for the padding columns)
-__global__ __launch_bounds__(256) void k_wb_rhs(int ld, int k_old, int k_new, const int *__restrict__ rows, const int *__restrict__ arp,
-                                                const int *__restrict__ aci, const double *__restrict__ aval, double *__restrict__ X) {
-    double *col = X + (size_t)(k_old + blockIdx.x) * ld;
-    for (int i = threadIdx.x; i < ld; i += blockDim.x) col[i] = 0.0;
-    __syncthreads();
-    if ((int)blockIdx.x >= k_new) return;
-    const int r = rows[k_old + blockIdx.x];
-    for (int e = arp[r] + threadIdx.x; e < arp[r + 1]; e += blockDim.x) col[aci[e]] = aval[e];
-}
-// G(a,b) = A(rows[a],:) Z(:,b) for the new columns b (and, by symmetry, the new rows)
-__global__ __launch_bounds__(64) void k_wb_G(int k_old, const int *__restrict__ rows, const int *__restrict__ arp, const int *__restrict__ aci,
-                                             const double *__restrict__ aval, const double *__restrict__ Z, int ld, double *__restrict__ G) {
-    const int a = blockIdx.x, b = k_old + blockIdx.y;
-    if (a > b) return;
-    const int r = rows[a];
-    const double *zc = Z + (size_t)b * ld;
-    double sacc = 0.0;
-    for (int e = arp[r] + threadIdx.x; e < arp[r + 1]; e += 64) sacc += aval[e] * zc[aci[e]];
-    sacc = wave_sum(sacc);
-    if (threadIdx.x == 0) { G[a * WB_MAX + b] = sacc; G[b * WB_MAX + a] = sacc; }
-}
-// v_a = A(rows[a],:) z0,  w_a = d - d_fact at that row
-__global__ __launch_bounds__(64) void k_wb_v(const int *__restrict__ rows, const int *__restrict__ arp, const int *__restrict__ aci,
-                                             const double *__restrict__ aval, const double *__restrict__ z0, const double *__restrict__ dw,
-                                             const double *__restrict__ dfact, double *__restrict__ v, double *__restrict__ w) {
-    const int a = blockIdx.x, r = rows[a];
-    double sacc = 0.0;
-    for (int e = arp[r] + threadIdx.x; e < arp[r + 1]; e += 64) sacc += aval[e] * z0[aci[e]];
-    sacc = wave_sum(sacc);
-    if (threadIdx.x == 0) { v[a] = sacc; w[a] = dw[r] - dfact[r]; }
-}
-// t = (I + W G)^-1 W v by Gauss-Jordan elimination with partial pivoting, all in LDS (k <= WB_MAX)
-__global__ __launch_bounds__(1024) void k_wb_lu(int k, const double *__restrict__ G, const double *__restrict__ w, const double *__restrict__ v,
-                                                double *__restrict__ t) {
-    extern __shared__ double smr[];
-    const int S = k + 2;                                  // row stride: k columns + right-hand side (+1 keeps it even/odd mixed)
-    double *M = smr;
-    __shared__ double red_v[16]; __shared__ int red_i[16]; __shared__ int piv_s; __shared__ double piv_inv, piv_min;
-    const int tid = threadIdx.x;
-    if (tid == 0) piv_min = 1.0;
-    for (int e = tid; e < k * (k + 1); e += 1024) {
-        const int a = e / (k + 1), b = e % (k + 1);
-        M[a * S + b] = b < k ? ((a == b ? 1.0 : 0.0) + w[a] * G[a * WB_MAX + b]) : w[a] * v[a];
-    }
-    __syncthreads();
-    for (int j = 0; j < k; j++) {
-        // pivot: largest |M[r][j]|, r >= j (ties -> smallest r)
-        double best = -1.0; int bi = j;
-        for (int r = j + tid; r < k; r += 1024) { const double x = fabs(M[r * S + j]); if (x > best) { best = x; bi = r; } }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ob = __shfl_down(best, off); const int oi = __shfl_down(bi, off);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        if ((tid & 63) == 0) { red_v[tid >> 6] = best; red_i[tid >> 6] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            double bb = red_v[0]; int ii = red_i[0];
-            for (int q = 1; q < 16; q++) if (red_v[q] > bb || (red_v[q] == bb && red_i[q] < ii)) { bb = red_v[q]; ii = red_i[q]; }
-            piv_s = ii; piv_inv = 1.0 / M[ii * S + j];
-            if (!(bb >= piv_min)) piv_min = bb;            // NaN-propagating minimum of |pivot|
-        }
-        __syncthreads();
-        const int p = piv_s; const double pinv = piv_inv;
-        if (p != j) for (int c = j + tid; c <= k; c += 1024) { const double x = M[j * S + c]; M[j * S + c] = M[p * S + c]; M[p * S + c] = x; }
-        __syncthreads();
-        // eliminate column j from every other row; columns j+1..k (k = right-hand side)
-        const int ncol = k - j;                            // columns j+1 .. k
-        for (int e = tid; e < k * ncol; e += 1024) {
-            const int r = e / ncol, c = j + 1 + e % ncol;
-            if (r != j) M[r * S + c] -= (M[r * S + j] * pinv) * M[j * S + c];
-        }
-        __syncthreads();
-        for (int c = j + 1 + tid; c <= k; c += 1024) M[j * S + c] *= pinv;
-        __syncthreads();
-    }
-    for (int a = tid; a < k; a += 1024) t[a] = M[a * S + k];
-    if (tid == 0) t[WB_MAX] = piv_min;                     // M = I at k = 0 weight change: pivots near 1 mean a benign update
-}
-// dx = z0 - Z t
-__global__ void k_wb_apply(int n, int ld, int k, const double *__restrict__ Z, const double *__restrict__ t, const double *__restrict__ z0,
-                           double *__restrict__ dx) {
-    __shared__ double ts[WB_MAX];
-    for (int a = threadIdx.x; a < k; a += blockDim.x) ts[a] = t[a];
-    __syncthreads();
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        double sacc = 0.0;
-        for (int a = 0; a < k; a++) sacc += Z[(size_t)a * ld + j] * ts[a];
-        dx[j] = z0[j] - sacc;
-    }
-}
-__global__ void k_dense_load_rhs(int n, int ld, const double *__restrict__ b, double *__restrict__ x) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ld; i += gridDim.x * blockDim.x) x[i] = i < n ? b[i] : 0.0;
-}
-__global__ void k_dense_scale_d(int ld, const double *__restrict__ z, const double *__restrict__ Dg, double *__restrict__ y) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ld; i += gridDim.x * blockDim.x) y[i] = z[i] / Dg[i];
-}
-
-// ================================================================================================
-// host side of the backend
-// ================================================================================================
-template <class T>
-static int dev_alloc(QpdoDev *d, T **p, size_t count) {
-    void *q = nullptr;
-    size_t bytes = (count ? count : 1) * sizeof(T);
-    HIPCHK(hipMalloc(&q, bytes));
-    HIPCHK(hipMemsetAsync(q, 0, bytes, d->stream));
-    d->allocs.push_back(q);
-    *p = (T *)q;
-    return 0;
-}
-static int pick_tpr(const DevCsr &M) {
-    const double avg = M.nrows ? (double)M.nnz / (double)M.nrows : 0.0;
-    if (avg > 48) return 64;
-    if (avg > 24) return 32;
-    if (avg > 12) return 16;
-    if (avg > 6) return 8;
-    return 4;
-}
-static int upload_csr(QpdoDev *d, DevCsr *M, const QdevCsr *h) {
-    M->nrows = h->nrows; M->ncols = h->ncols; M->nnz = h->nnz;
-    int rc;
-    if ((rc = dev_alloc(d, &M->rp, (size_t)h->nrows + 1))) return rc;
-    if ((rc = dev_alloc(d, &M->ci, (size_t)h->nnz))) return rc;
-    if ((rc = dev_alloc(d, &M->val, (size_t)h->nnz))) return rc;
-    HIPCHK(hipMemcpyAsync(M->rp, h->rp, ((size_t)h->nrows + 1) * sizeof(int), hipMemcpyHostToDevice, d->stream));
-    if (h->nnz) {
-        HIPCHK(hipMemcpyAsync(M->ci, h->ci, (size_t)h->nnz * sizeof(int), hipMemcpyHostToDevice, d->stream));
-        HIPCHK(hipMemcpyAsync(M->val, h->val, (size_t)h->nnz * sizeof(double), hipMemcpyHostToDevice, d->stream));
-    }
-    M->tpr = pick_tpr(*M);
-    return 0;
-}
-static int read_ctrl(QpdoDev *d);
-// decide whether M streams from HBM (then use the LDS-staged kernel) and build its slab pointers
-// arrays of the slab-major image (two padding entries: the 16-byte loads may touch one element past a segment)
-static int slab_major_alloc(QpdoDev *d, DevCsr *M, size_t nnz_cap, size_t nseg, bool with_f32 = false) {
-    const size_t PAD = 4;       // the vector loads may touch up to three elements past a segment
-    int rc = dev_alloc(d, &M->vsm, nnz_cap + PAD);
-    if (!rc) rc = M->ci16 ? dev_alloc(d, &M->i16sm, nnz_cap + PAD) : dev_alloc(d, &M->cism, nnz_cap + PAD);
-    if (!rc && with_f32 && M->ci16) rc = dev_alloc(d, &M->vsm32, nnz_cap + PAD);
-    if (!rc) rc = dev_alloc(d, &M->seg, nseg > 0 ? nseg : 1);
-    if (!rc) {
-        hipError_t e = hipMemsetAsync(M->vsm + nnz_cap, 0, PAD * sizeof(double), d->stream);
-        if (e == hipSuccess) e = M->i16sm ? hipMemsetAsync(M->i16sm + nnz_cap, 0, PAD * sizeof(unsigned short), d->stream) : hipMemsetAsync(M->cism + nnz_cap, 0, PAD * sizeof(int), d->stream);
-        if (e == hipSuccess && M->vsm32) e = hipMemsetAsync(M->vsm32 + nnz_cap, 0, PAD * sizeof(float), d->stream);
-        if (e != hipSuccess) rc = set_err(e, "hipMemsetAsync", __LINE__);
-    }
-    M->sm_dirty = 1;
-    return rc;
-}
-static int setup_slabs(QpdoDev *d, DevCsr *M) {
-    const char *tp = getenv("QPDO_SLAB_TPR");
-    if (tp && (atoi(tp) == 8 || atoi(tp) == 16 || atoi(tp) == 32)) g_slab_tpr = atoi(tp);
-    const char *force = getenv("QPDO_SPMV");            // "slab" | "plain" | unset (auto)
-    const double bytes = 12.0 * (double)M->nnz;
-    bool want = bytes >= 192.0 * 1024 * 1024 && M->nrows >= 4096;   // beyond what L2 + Infinity Cache keep resident
-    if (force && !strcmp(force, "slab")) want = M->nrows >= 256;
-    if (force && !strcmp(force, "plain")) want = false;
-    M->use_slab = 0;
-    if (!want) return 0;
-    const int NWG = 256;                                 // one workgroup per CU
-    M->rows_per_wg = (M->nrows + NWG - 1) / NWG;
-    M->slab_grid = (M->nrows + M->rows_per_wg - 1) / M->rows_per_wg;
-    const long long lds_doubles = (160 * 1024 - 1024) / 8 - M->rows_per_wg;
-    if (lds_doubles < 1024) return 0;
-    int nslabs = (int)((M->ncols + lds_doubles - 1) / lds_doubles);
-    if (nslabs < 1) nslabs = 1;
-    int W = (M->ncols + nslabs - 1) / nslabs;
-    W = (W + 63) & ~63;
-    if (W > lds_doubles) { nslabs++; W = ((M->ncols + nslabs - 1) / nslabs + 63) & ~63; }
-    M->nslabs = nslabs; M->W = W;
-    int rc = dev_alloc(d, &M->sp, (size_t)M->nrows * (nslabs + 1));
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_ctrl_set_int, dim3(1), dim3(1), 0, d->stream, d->ctrl, C_VIOL, 0);
-    hipLaunchKernelGGL(k_build_slab_ptr, dim3(vgrid(M->nrows)), dim3(BLK), 0, d->stream, M->nrows, M->rp, M->ci, nslabs, W, M->sp, &d->ctrl->cnt[C_VIOL]);
-    rc = read_ctrl(d); if (rc) return rc;
-    M->use_slab = d->hctrl->cnt[C_VIOL] ? 0 : 1;          // unsorted rows: keep the plain kernel
-    const char *i16 = getenv("QPDO_IDX16");
-    if (M->use_slab && W < 65536 && !(i16 && !strcmp(i16, "0"))) {
-        rc = dev_alloc(d, &M->ci16, (size_t)M->nnz);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_fill_ci16, dim3(2048), dim3(BLK), 0, d->stream, M->nnz, M->ci, W, M->ci16);
-    }
-    if (M->use_slab) { rc = slab_major_alloc(d, M, (size_t)M->nnz, (size_t)M->nrows * nslabs); if (rc) return rc; }
-    return 0;
-}
-static void slab_major_build(QpdoDev *d, const DevCsr &M) {
-    hipLaunchKernelGGL(k_slab_seg, dim3(M.slab_grid), dim3(1024), 0, d->stream, M.nrows, M.nslabs, M.rows_per_wg, (const int *)M.sp, M.seg);
-    hipLaunchKernelGGL(k_slab_permute, dim3(2048), dim3(256), 0, d->stream, M.nrows, M.nslabs, M.W, (const int *)M.sp, (const int2 *)M.seg,
-                       (const int *)M.ci, (const unsigned short *)M.ci16, (const double *)M.val, M.vsm, M.i16sm, M.cism, M.vsm32);
-    M.sm_dirty = 0;
-}
-static int read_ctrl(QpdoDev *d) {
-    HIPCHK(hipMemcpyAsync(d->hctrl, d->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    return 0;
-}
-static inline double nrm_of(const Ctrl *c, int slot) {
-    double v; u64 b = c->nrm[slot]; memcpy(&v, &b, 8); return v;
-}
-#define LAUNCH(kernel, grid, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLK), 0, d->stream, __VA_ARGS__)
-
-// ---- collectives ----------------------------------------------------------------------------------------
-static int comm_allreduce(QpdoDev *d, double *dev, size_t cnt, int op /*0 sum, 1 max*/) {
-    Comm &c = d->comm;
-    if (c.world <= 1 || cnt == 0) return 0;
-    if (c.mode == 2) {
-        ncclResult_t r = ncclAllReduce(dev, dev, cnt, ncclDouble, op ? ncclMax : ncclSum, c.nccl, d->stream);
-        if (r != ncclSuccess) { snprintf(g_err, sizeof(g_err), "ncclAllReduce: %s", ncclGetErrorString(r)); return -1; }
-        return 0;
-    }
-    if (c.mode == 1) {
-        if (cnt > c.hcap) { snprintf(g_err, sizeof(g_err), "allreduce staging too small"); return -1; }
-        HIPCHK(hipMemcpyAsync(c.hbuf, dev, cnt * 8, hipMemcpyDeviceToHost, d->stream));
-        HIPCHK(hipStreamSynchronize(d->stream));
-        c.fn(c.ctx, c.hbuf, (long)cnt, op);
-        HIPCHK(hipMemcpyAsync(dev, c.hbuf, cnt * 8, hipMemcpyHostToDevice, d->stream));
-        return 0;
-    }
-    snprintf(g_err, sizeof(g_err), "distributed workspace without a communicator");
-    return -1;
-}
-// row epilogue applied after the exchange: the same functors the fused single-GPU products use
-template <class Epi>
-__global__ __launch_bounds__(256) void k_epi_apply(int nrows, const double *__restrict__ sums, Epi epi) {
-    __shared__ double sm[32];
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) epi.row(r, sums[r]);
-    epi.finish(sm);
-}
-// y = A x with epilogue (global row space m); world > 1: local rows, sum all-reduce, then the epilogue
-template <class Epi>
-static int spmv_A(QpdoDev *d, const double *x, Epi epi, bool partials) {
-    if (d->comm.world <= 1) { launch_spmv(d, d->Ar, x, epi, partials); return 0; }
-    HIPCHK(hipMemsetAsync(d->dist_tmp, 0, (size_t)d->m * 8, d->stream));
-    launch_spmv(d, d->Ar, x, EpiStore{d->dist_tmp + d->m0}, false);
-    int rc = comm_allreduce(d, d->dist_tmp, (size_t)d->m, 0); if (rc) return rc;
-    hipLaunchKernelGGL((k_epi_apply<Epi>), dim3(vgrid(d->m)), dim3(BLK), 0, d->stream, d->m, (const double *)d->dist_tmp, epi);
-    return 0;
-}
-static inline int pgrid_A(QpdoDev *d) { return d->comm.world <= 1 ? spmv_pgrid(d->Ar) : vgrid(d->m); }
-// y = A' x with epilogue (x is a global m-vector); world > 1: local columns, sum all-reduce, then the epilogue
-template <class Epi>
-static int spmv_At(QpdoDev *d, const double *x, Epi epi, bool partials) {
-    if (d->comm.world <= 1) { launch_spmv(d, d->At, x, epi, partials); return 0; }
-    launch_spmv(d, d->At, x + d->m0, EpiStore{d->dist_tmp}, false);
-    int rc = comm_allreduce(d, d->dist_tmp, (size_t)d->n, 0); if (rc) return rc;
-    hipLaunchKernelGGL((k_epi_apply<Epi>), dim3(vgrid(d->n)), dim3(BLK), 0, d->stream, d->n, (const double *)d->dist_tmp, epi);
-    return 0;
-}
-// PCG pieces of the distributed operator
-__global__ void k_pcg_dist_finish(int n, const int *__restrict__ done, const double *__restrict__ part, const double *__restrict__ p,
-                                  double sigma_f, double *__restrict__ Kp, double *__restrict__ p_pKp) {
-    __shared__ double sm[32];
-    if (*done) return;
-    double acc = 0.0;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const double v = part[j] + sigma_f * p[j];
-        Kp[j] = v; acc += p[j] * v;
-    }
-    double t = block_sum(acc, sm);
-    if (threadIdx.x == 0) p_pKp[blockIdx.x] = t;
-}
-struct EpiAddTo {                          // out[r + off] += s   (partial operator rows)
-    double *out; int off;
-    __device__ bool skip(int) const { return false; }
-    __device__ void row(int r, double s) { out[r + off] += s; }
-    __device__ void finish(double *) {}
-};
-__global__ void k_add3(int n, const double *__restrict__ a, const double *__restrict__ b, double c, double *__restrict__ out) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = a[i] + b[i] + c;
-}
+#include "dev/state.inc"
+#include "dev/helpers.inc"
+#include "dev/spmv.inc"
+#include "dev/vector.inc"
+#include "dev/pcg_kernels.inc"
+#include "dev/linesearch.inc"
+#include "dev/dense_kernels.inc"
+#include "dev/host_core.inc"
 
 extern "C" {
-
-int qdev_rccl_unique_id(void *out128) {
-    ncclUniqueId id;
-    if (ncclGetUniqueId(&id) != ncclSuccess) return -1;
-    memcpy(out128, &id, sizeof(id) < 128 ? sizeof(id) : 128);
-    return 0;
-}
-int qdev_device_count(void) { int c = 0; if (hipGetDeviceCount(&c) != hipSuccess) return 0; return c; }
-const char *qdev_last_error(void) { return g_err; }
-
-int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *Ar, const QdevCsr *At, const QdevCsr *Qf,
-                const double *q, const double *l, const double *u) {
-    QdevDist none; memset(&none, 0, sizeof(none));
-    none.world = 1; none.mloc = m; none.nloc = n;
-    return qdev_create_dist(out, device, n, m, Ar, At, Qf, (const QdevCsr *)nullptr, q, l, u, &none);
-}
-int qdev_create_dist(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *Ar, const QdevCsr *At, const QdevCsr *Qf,
-                     const QdevCsr *Qs, const double *q, const double *l, const double *u, const QdevDist *dist) {
-    *out = nullptr;
-    HIPCHK(hipSetDevice(device));
-    QpdoDev *d = new QpdoDev();
-    d->device = device; d->n = n; d->m = m;
-    d->m0 = dist->m0; d->mloc = dist->mloc; d->n0 = dist->n0; d->nloc = dist->nloc;
-    d->comm.rank = dist->rank; d->comm.world = dist->world; d->comm.fn = dist->fn; d->comm.ctx = dist->ctx;
-    d->comm.mode = dist->world > 1 ? (dist->fn ? 1 : 2) : 0;
-    int rc = 0;
-    hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete d; return set_err(e, "hipStreamCreate", __LINE__); }
-#define A_(p, cnt) if (!rc) rc = dev_alloc(d, &d->p, (size_t)(cnt))
-    if (!rc) rc = upload_csr(d, &d->Ar, Ar);
-    if (!rc) rc = upload_csr(d, &d->At, At);
-    if (!rc) rc = upload_csr(d, &d->Qf, Qf);
-    if (!rc && Qs && dist->world > 1) rc = upload_csr(d, &d->Qs, Qs);
-    A_(x, n); A_(xbar, n); A_(Qx, n); A_(Aty, n); A_(q, n); A_(df, n); A_(res_dual, n); A_(res_dual_in, n); A_(rhs, n);
-    A_(dx, n); A_(Qdx, n); A_(Atdy, n); A_(D, n); A_(Dinv, n);
-    A_(pc_r, n); A_(pc_z, n); A_(pc_p, n); A_(pc_Kp, n); A_(pc_diag, n); A_(tmp_n, n);
-    A_(y, m); A_(ybar, m); A_(Ax, m); A_(l, m); A_(u, m); A_(mu, m); A_(isq, m); A_(w, m); A_(res_prim, m);
-    A_(res_prim_old, m); A_(res_prim_in, m); A_(dy, m); A_(Adx, m); A_(d, m); A_(E, m); A_(Einv, m); A_(pc_t, m);
-    A_(at_scale, m); A_(tmp_m, m);
-    A_(active, m); A_(active_old, m); A_(mu_changed, m);
-    const size_t M2 = 2 * (size_t)m;
-    A_(ls_delta, M2); A_(ls_alpha, M2); A_(ls_pa, M2); A_(ls_pb, M2);
-    A_(ls_key[0], M2); A_(ls_key[1], M2); A_(ls_idx[0], M2); A_(ls_idx[1], M2);
-    d->rs_nblocks = (int)((M2 + RS_TILE - 1) / RS_TILE); if (d->rs_nblocks < 1) d->rs_nblocks = 1;
-    A_(rs_hist, (size_t)256 * d->rs_nblocks);
-    d->ls_nblk = (int)((M2 + LS_TILE - 1) / LS_TILE); if (d->ls_nblk < 1) d->ls_nblk = 1;
-    A_(ls_bt, (size_t)2 * d->ls_nblk + 2);
-    A_(ctrl, 1); A_(part, (size_t)P_COUNT * PGRID);
-    A_(ctrl2, 1); A_(part2, (size_t)3 * PGRID);
-    A_(s_x, m); A_(s_r, m); A_(s_z, m); A_(s_p, m); A_(s_Sp, m); A_(s_diag, m); A_(s_v, m);
-#undef A_
-    if (!rc) { e = hipHostMalloc((void **)&d->hctrl, sizeof(Ctrl), hipHostMallocDefault); if (e != hipSuccess) rc = set_err(e, "hipHostMalloc", __LINE__); }
-    if (!rc) { e = hipHostMalloc((void **)&d->hctrl2, sizeof(Ctrl), hipHostMallocDefault); if (e != hipSuccess) rc = set_err(e, "hipHostMalloc", __LINE__); }
-    if (!rc) { e = hipEventCreate(&d->ev0); if (e == hipSuccess) e = hipEventCreate(&d->ev1); if (e != hipSuccess) rc = set_err(e, "hipEventCreate", __LINE__); }
-    if (!rc) {
-        e = hipMemcpyAsync(d->q, q, (size_t)n * 8, hipMemcpyHostToDevice, d->stream);
-        if (e == hipSuccess && m) e = hipMemcpyAsync(d->l, l, (size_t)m * 8, hipMemcpyHostToDevice, d->stream);
-        if (e == hipSuccess && m) e = hipMemcpyAsync(d->u, u, (size_t)m * 8, hipMemcpyHostToDevice, d->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
-        if (e != hipSuccess) rc = set_err(e, "upload", __LINE__);
-    }
-    if (!rc) rc = setup_slabs(d, &d->Ar);
-    if (!rc) rc = setup_slabs(d, &d->At);
-    if (!rc) rc = setup_slabs(d, &d->Qf);
-    if (!rc && d->comm.world > 1 && d->Qs.nrows > 0) rc = setup_slabs(d, &d->Qs);
-    if (!rc && d->comm.world > 1) {
-        const size_t mx = (size_t)(n > m ? n : m);
-        rc = dev_alloc(d, &d->dist_tmp, mx);
-        if (!rc) rc = dev_alloc(d, &d->Kp_part, (size_t)n);
-        if (!rc) rc = dev_alloc(d, &d->zeros_n, (size_t)n);
-        if (!rc && d->comm.mode == 1) { hipError_t e2 = hipHostMalloc((void **)&d->comm.hbuf, mx * 8, hipHostMallocDefault); if (e2 != hipSuccess) rc = set_err(e2, "hipHostMalloc", __LINE__); else d->comm.hcap = mx; }
-        if (!rc && d->comm.mode == 2) {
-            ncclUniqueId id; memcpy(&id, dist->nccl_id, sizeof(id));
-            ncclResult_t r = ncclCommInitRank(&d->comm.nccl, dist->world, id, dist->rank);
-            if (r != ncclSuccess) { snprintf(g_err, sizeof(g_err), "ncclCommInitRank: %s", ncclGetErrorString(r)); rc = -1; }
-        }
-    }
-    if (!rc) {   // per-pass compact copies used by PCG
-        d->Arc = d->Ar; d->Arc.rp = nullptr; d->Arc.ci = nullptr; d->Arc.val = nullptr; d->Arc.sp = nullptr; d->Arc.ci16 = nullptr;
-        d->Atc = d->At; d->Atc.rp = nullptr; d->Atc.ci = nullptr; d->Atc.val = nullptr; d->Atc.sp = nullptr; d->Atc.ci16 = nullptr;
-        d->Arc.vsm = nullptr; d->Arc.i16sm = nullptr; d->Arc.cism = nullptr; d->Arc.seg = nullptr; d->Arc.vsm32 = nullptr;
-        d->Atc.vsm = nullptr; d->Atc.i16sm = nullptr; d->Atc.cism = nullptr; d->Atc.seg = nullptr; d->Atc.vsm32 = nullptr;
-        { const char *f32 = getenv("QPDO_PCG_INNER_F32"); d->inner_f32 = (f32 && atoi(f32) != 0) ? 1 : 0; }
-        rc = dev_alloc(d, &d->Arc.rp, (size_t)m + 1);
-        if (!rc) rc = dev_alloc(d, &d->Arc.ci, (size_t)Ar->nnz);
-        if (!rc) rc = dev_alloc(d, &d->Arc.val, (size_t)Ar->nnz);
-        if (!rc && d->Ar.use_slab) rc = dev_alloc(d, &d->Arc.sp, (size_t)m * (d->Ar.nslabs + 1));
-        if (!rc && d->Ar.ci16) rc = dev_alloc(d, &d->Arc.ci16, (size_t)Ar->nnz);
-        if (!rc && d->Ar.use_slab) rc = slab_major_alloc(d, &d->Arc, (size_t)Ar->nnz, (size_t)m * d->Ar.nslabs, d->inner_f32 != 0);
-        if (!rc) rc = dev_alloc(d, &d->Atc.rp, (size_t)n + 1);
-        if (!rc) rc = dev_alloc(d, &d->Atc.ci, (size_t)At->nnz);
-        if (!rc) rc = dev_alloc(d, &d->Atc.val, (size_t)At->nnz);
-        if (!rc && d->At.use_slab) rc = dev_alloc(d, &d->Atc.sp, (size_t)n * (d->At.nslabs + 1));
-        if (!rc && d->At.ci16) rc = dev_alloc(d, &d->Atc.ci16, (size_t)At->nnz);
-        if (!rc && d->At.use_slab) rc = slab_major_alloc(d, &d->Atc, (size_t)At->nnz, (size_t)n * d->At.nslabs, d->inner_f32 != 0);
-        if (!rc) rc = dev_alloc(d, &d->row_cnt, (size_t)(n > m ? n : m));
-        if (!rc) rc = dev_alloc(d, &d->cidx, (size_t)m);
-        if (!rc) rc = dev_alloc(d, &d->rowlist, (size_t)m);
-        if (!rc) rc = dev_alloc(d, &d->kcount, 4);
-        if (!rc) rc = dev_alloc(d, &d->dc, (size_t)m);
-        if (!rc) rc = dev_alloc(d, &d->tc, (size_t)m);
-        d->lds_doubles_At = (160 * 1024 - 1024) / 8 - d->At.rows_per_wg;
-        if (!rc) rc = dev_alloc(d, &d->qdiag, (size_t)n);
-        const char *df = getenv("QPDO_DEFLATE");
-        d->deflate = !(df && !strcmp(df, "0"));
-        int mx = 0;
-        for (int i = 0; i < Ar->nrows; i++) { const int len = Ar->rp[i + 1] - Ar->rp[i]; if (len > mx) mx = len; }
-        d->max_row_nnz_A = mx;
-        if (d->deflate && m > 0) {
-            d->Ath = DevCsr(); d->Ath.nrows = n; d->Ath.ncols = m;
-            if (!rc) rc = dev_alloc(d, &d->Ath.rp, (size_t)n + 1);
-            if (!rc) rc = dev_alloc(d, &d->Ath.ci, (size_t)DEFL_MAX * (mx > 0 ? mx : 1));
-            if (!rc) rc = dev_alloc(d, &d->Ath.val, (size_t)DEFL_MAX * (mx > 0 ? mx : 1));
-            if (!rc) rc = dev_alloc(d, &d->defl_hist, 32);
-            if (!rc) rc = dev_alloc(d, &d->defl_list, DEFL_MAX);
-            if (!rc) rc = dev_alloc(d, &d->defl_count, 1);
-            if (!rc) rc = dev_alloc(d, &d->defl_flag, (size_t)m);
-            if (!rc) rc = dev_alloc(d, &d->defl_t, (size_t)m);
-            if (!rc) rc = dev_alloc(d, &d->defl_S, (size_t)DEFL_MAX * DEFL_MAX);
-            if (!rc) rc = dev_alloc(d, &d->defl_Sinv, (size_t)DEFL_MAX * DEFL_MAX);
-            if (!rc) rc = dev_alloc(d, &d->defl_v, DEFL_MAX);
-        }
-    }
-    if (rc) { qdev_destroy(d); return rc; }
-    d->st.linsolve = 0;
-    *out = d;
-    return 0;
-}
-
-void qdev_destroy(QpdoDev *d) {
-    if (!d) return;
-    (void)hipSetDevice(d->device);
-    if (d->stream) (void)hipStreamSynchronize(d->stream);
-    for (void *p : d->allocs) (void)hipFree(p);
-    if (d->hctrl) (void)hipHostFree(d->hctrl);
-    if (d->hctrl2) (void)hipHostFree(d->hctrl2);
-    if (d->comm.hbuf) (void)hipHostFree(d->comm.hbuf);
-    if (d->comm.nccl) ncclCommDestroy(d->comm.nccl);
-    if (d->ev0) (void)hipEventDestroy(d->ev0);
-    if (d->ev1) (void)hipEventDestroy(d->ev1);
-    for (int i = 0; i < 2; i++) { if (d->evF[i]) (void)hipEventDestroy(d->evF[i]); if (d->evB[i]) (void)hipEventDestroy(d->evB[i]); }
-    if (d->stream2) (void)hipStreamDestroy(d->stream2);
-    if (d->stream) (void)hipStreamDestroy(d->stream);
-    delete d;
-}
-int qdev_sync(QpdoDev *d) { HIPCHK(hipSetDevice(d->device)); HIPCHK(hipStreamSynchronize(d->stream)); return 0; }
-
-int qdev_configure(QpdoDev *d, int linsolve, double pcg_tol, int pcg_maxit) {
-    const char *gr = getenv("QPDO_PCG_GRAPH");
-    if (gr && !strcmp(gr, "0")) d->pcg_graph = 0;
-    const char *mx = getenv("QPDO_DENSE_MAX_N");
-    if (mx && *mx) d->dense_max_n = atoi(mx);
-    const char *sc = getenv("QPDO_PCG_SCHUR");
-    if (sc && *sc) d->schur_mode = atoi(sc) != 0;
-    const char *ch = getenv("QPDO_DENSE_SOLVE");
-    if (ch && !strcmp(ch, "steps")) d->dense_chain = 0;
-    const char *lr = getenv("QPDO_DENSE_LOWRANK");
-    if (lr && *lr) d->wb_enable = atoi(lr) != 0;
-    if (!d->dense_chain) d->wb_enable = 0;                       // the refinement sweeps assume the one-launch solves
-    if (d->dense_max_n > 18000) d->dense_max_n = 18000;       // the assembly accumulator (n doubles) must fit in LDS
-    if (linsolve >= 0) d->linsolve = linsolve;
-    else d->linsolve = (d->n <= d->dense_max_n) ? 1 : 0;
-    if (d->linsolve == 1 && d->n > 18000) d->linsolve = 0;
-    if (d->comm.world > 1) { d->linsolve = 0; d->deflate = 0; }   // the dense factor and the Woodbury rows are not partitioned
-    if (pcg_tol > 0) d->pcg_tol = pcg_tol;
-    if (pcg_maxit > 0) d->pcg_maxit = pcg_maxit;
-    d->st.linsolve = d->linsolve;
-    return 0;
-}
-int qdev_get_stats(QpdoDev *d, QdevStats *out) { *out = d->st; return 0; }
-int qdev_get_ac_sample(QpdoDev *d, double *seconds_sum, double *bytes_sum, long *samples, long *schur_passes) {
-    *seconds_sum = d->ev_ac_ms * 1e-3; *bytes_sum = d->ev_ac_bytes; *samples = (long)d->ev_ac_n; *schur_passes = (long)d->schur_passes;
-    return 0;
-}
-int qdev_get_spmv_sample(QpdoDev *d, double *avg_seconds, long *samples) {
-    *samples = (long)d->ev_spmv_n;
-    *avg_seconds = d->ev_spmv_n ? d->ev_spmv_ms * 1e-3 / (double)d->ev_spmv_n : 0.0;
-    return 0;
-}
-int qdev_reset_stats(QpdoDev *d) { int ls = d->st.linsolve; d->st = QdevStats{}; d->st.linsolve = ls; d->ev_spmv_ms = 0; d->ev_spmv_n = 0; d->ev_ac_ms = 0; d->ev_ac_bytes = 0; d->ev_ac_n = 0; d->schur_passes = 0; return 0; }
-
-// ---- scaling (scaling.c:24-91) ------------------------------------------------------------------
-int qdev_scale_data(QpdoDev *d, int iters, int use_Qx, double *D_host, double *E_host, double *c_out) {
-    HIPCHK(hipSetDevice(d->device));
-    const int n = d->n, m = d->m;
-    LAUNCH(k_fill, vgrid(n), n, 1.0, d->D);
-    LAUNCH(k_fill, vgrid(m), m, 1.0, d->E);
-    const int gAt = spmv_grid(d->At, d->At.tpr, false), gAr = spmv_grid(d->Ar, d->Ar.tpr, false);
-    for (int it = 0; it < iters; it++) {
-        // column norms of A = row norms of CSR(A'); row norms of A = row norms of CSR(A)
-        DISPATCH_TPR(d->At, k_row_absmax, gAt, n, d->At.rp, d->At.val, d->tmp_n);
-        if (d->comm.world > 1) {   // max over the row slices; row norms gathered through a sum with zero padding
-            int rcx = comm_allreduce(d, d->tmp_n, (size_t)n, 1); if (rcx) return rcx;
-            HIPCHK(hipMemsetAsync(d->tmp_m, 0, (size_t)m * 8, d->stream));
-        }
-        DISPATCH_TPR(d->Ar, k_row_absmax, gAr, d->mloc, d->Ar.rp, d->Ar.val, d->tmp_m + d->m0);
-        if (d->comm.world > 1) { int rcx = comm_allreduce(d, d->tmp_m, (size_t)m, 0); if (rcx) return rcx; }
-        LAUNCH(k_ruiz_factor, vgrid(n), n, d->tmp_n, d->D);
-        LAUNCH(k_ruiz_factor, vgrid(m), m, d->tmp_m, d->E);
-        // A <- E A D: (a * E_i) * D_j on both stored copies
-        DISPATCH_TPR(d->Ar, k_scale_rows_cols, gAr, d->mloc, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)(d->tmp_m + d->m0), (const double *)nullptr,
-                     (const double *)nullptr, (const double *)d->tmp_n);
-        DISPATCH_TPR(d->At, k_scale_rows_cols, gAt, n, d->At.rp, d->At.ci, d->At.val, (const double *)nullptr, (const double *)(d->tmp_m + d->m0),
-                     (const double *)d->tmp_n, (const double *)nullptr);
-    }
-    const int gQ = spmv_grid(d->Qf, d->Qf.tpr, false);
-    DISPATCH_TPR(d->Qf, k_scale_sym, gQ, n, d->Qf.rp, d->Qf.ci, d->Qf.val, (const double *)d->D);
-    if (d->comm.world > 1 && d->Qs.nnz) hipLaunchKernelGGL(k_scale_sym_rows, dim3(vgrid(d->nloc)), dim3(BLK), 0, d->stream, d->nloc, d->n0, d->Qs.rp, d->Qs.ci, d->Qs.val, (const double *)d->D);
-    d->qdiag_valid = 0; d->dense_valid = 0; d->dense_factored = 0;
-    d->Ar.sm_dirty = d->At.sm_dirty = d->Qf.sm_dirty = d->Qs.sm_dirty = 1;
-    LAUNCH(k_mul, vgrid(n), n, d->D, d->q, d->q);                    // q <- D q
-    // cost scaling: c = 1 / max(1, ||Qx + q||inf)
-    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
-    LAUNCH(k_absmax_axpy, vgrid(n), n, (const double *)d->q, use_Qx ? (const double *)d->Qx : (const double *)nullptr, 1.0, d->ctrl, N_A);
-    int rc = read_ctrl(d); if (rc) return rc;
-    const double nq = nrm_of(d->hctrl, N_A);
-    const double c = 1 / (1.0 > nq ? 1.0 : nq);
-    // q <- c q (vec_self_mult_scalar), Q <- c Q
-    LAUNCH(k_scal, vgrid(n), n, c, d->q);
-    if (d->Qf.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qf.nnz, d->Qf.val, c);
-    if (d->comm.world > 1 && d->Qs.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qs.nnz, d->Qs.val, c);
-    d->Ar.sm_dirty = d->At.sm_dirty = d->Qf.sm_dirty = d->Qs.sm_dirty = 1;      // values changed: the slab-major images are stale
-    HIPCHK(hipMemcpyAsync(D_host, d->D, (size_t)n * 8, hipMemcpyDeviceToHost, d->stream));
-    if (m) HIPCHK(hipMemcpyAsync(E_host, d->E, (size_t)m * 8, hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    *c_out = c;
-    return 0;
-}
-int qdev_set_scaling(QpdoDev *d, int scaled, const double *D, const double *Dinv, const double *E, const double *Einv, double c, double cinv) {
-    HIPCHK(hipSetDevice(d->device));
-    d->scaled = scaled; d->sc_c = c; d->sc_cinv = cinv;
-    if (scaled) {
-        HIPCHK(hipMemcpyAsync(d->D, D, (size_t)d->n * 8, hipMemcpyHostToDevice, d->stream));
-        HIPCHK(hipMemcpyAsync(d->Dinv, Dinv, (size_t)d->n * 8, hipMemcpyHostToDevice, d->stream));
-        if (d->m) {
-            HIPCHK(hipMemcpyAsync(d->E, E, (size_t)d->m * 8, hipMemcpyHostToDevice, d->stream));
-            HIPCHK(hipMemcpyAsync(d->Einv, Einv, (size_t)d->m * 8, hipMemcpyHostToDevice, d->stream));
-        }
-        HIPCHK(hipStreamSynchronize(d->stream));
-    }
-    return 0;
-}
-int qdev_upload_bounds(QpdoDev *d, const double *l, const double *u) {
-    HIPCHK(hipSetDevice(d->device));
-    if (d->m) {
-        if (l) HIPCHK(hipMemcpyAsync(d->l, l, (size_t)d->m * 8, hipMemcpyHostToDevice, d->stream));
-        if (u) HIPCHK(hipMemcpyAsync(d->u, u, (size_t)d->m * 8, hipMemcpyHostToDevice, d->stream));
-    }
-    HIPCHK(hipStreamSynchronize(d->stream));
-    return 0;
-}
-int qdev_upload_q(QpdoDev *d, const double *q) {
-    HIPCHK(hipSetDevice(d->device));
-    HIPCHK(hipMemcpyAsync(d->q, q, (size_t)d->n * 8, hipMemcpyHostToDevice, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    return 0;
-}
-int qdev_download_q(QpdoDev *d, double *q) {
-    HIPCHK(hipSetDevice(d->device));
-    HIPCHK(hipMemcpyAsync(q, d->q, (size_t)d->n * 8, hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    return 0;
-}
-int qdev_scale_Q_values(QpdoDev *d, double factor) {
-    HIPCHK(hipSetDevice(d->device));
-    d->qdiag_valid = 0; d->dense_valid = 0; d->dense_factored = 0;
-    d->Qf.sm_dirty = d->Qs.sm_dirty = 1;
-    if (d->comm.world > 1 && d->Qs.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qs.nnz, d->Qs.val, factor);
-    if (d->Qf.nnz) hipLaunchKernelGGL(k_scale_vals, dim3(2048), dim3(BLK), 0, d->stream, d->Qf.nnz, d->Qf.val, factor);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-static double *vec_by_id(QpdoDev *d, int which, size_t *len) {
-    switch (which) {
-        case 0: *len = d->n; return d->x;
-        case 1: *len = d->n; return d->Qx;
-        case 2: *len = d->m; return d->y;
-        case 3: *len = d->m; return d->mu;
-        case 4: *len = d->m; return d->d;
-        case 5: *len = d->n; return d->dx;
-        case 6: *len = d->m; return d->dy;
-        case 7: *len = d->m; return d->Ax;
-        case 8: *len = d->n; return d->Aty;
-        case 9: *len = d->m; return d->l;
-        case 10: *len = d->m; return d->u;
-    }
-    *len = 0; return nullptr;
-}
-int qdev_download_vec(QpdoDev *d, int which, double *dst) {
-    HIPCHK(hipSetDevice(d->device));
-    size_t len; double *p = vec_by_id(d, which, &len);
-    if (!p) return -1;
-    if (len) HIPCHK(hipMemcpyAsync(dst, p, len * 8, hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    return 0;
-}
-int qdev_upload_vec(QpdoDev *d, int which, const double *src) {
-    HIPCHK(hipSetDevice(d->device));
-    size_t len; double *p = vec_by_id(d, which, &len);
-    if (!p) return -1;
-    if (len) HIPCHK(hipMemcpyAsync(p, src, len * 8, hipMemcpyHostToDevice, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    return 0;
-}
-
-// ---- warm start (qpdo.c:217-299, iteration.c:98-122) ---------------------------------------------
-int qdev_objective(QpdoDev *d, int proximal, double sigma, double c_const, double *objective) {
-    HIPCHK(hipSetDevice(d->device));
-    const int g = vgrid(d->n);
-    LAUNCH(k_objective, g, d->n, proximal, sigma, d->x, d->Qx, d->q, d->part + P_OBJ * PGRID);
-    LAUNCH(k_reduce_to_ctrl, 1, d->part + P_OBJ * PGRID, g, d->ctrl, V_OBJ);
-    int rc = read_ctrl(d); if (rc) return rc;
-    double obj = d->hctrl->val[V_OBJ];
-    if (d->scaled) obj *= d->sc_cinv;
-    obj += c_const;
-    *objective = obj;
-    return 0;
-}
-int qdev_warm_start(QpdoDev *d, const double *x_ws, const double *y_ws, int proximal, double sigma, double mu_min,
-                    double c_const, double *objective) {
-    HIPCHK(hipSetDevice(d->device));
-    const int n = d->n, m = d->m;
-    (void)mu_min;
-    *objective = 0.0;
-    if (x_ws) {
-        HIPCHK(hipMemcpyAsync(d->tmp_n, x_ws, (size_t)n * 8, hipMemcpyHostToDevice, d->stream));
-        LAUNCH(k_ws_x, vgrid(n), n, d->scaled, d->tmp_n, d->Dinv, d->x, d->xbar);
-        launch_spmv(d, d->Qf, d->x, EpiQpure{d->x, sigma, proximal, d->Qx}, false);
-        { int rc2 = spmv_A(d, d->x, EpiStore{d->Ax}, false); if (rc2) return rc2; }
-        int rc = qdev_objective(d, proximal, sigma, c_const, objective); if (rc) return rc;
-    } else {
-        HIPCHK(hipMemsetAsync(d->x, 0, (size_t)n * 8, d->stream));
-        HIPCHK(hipMemsetAsync(d->xbar, 0, (size_t)n * 8, d->stream));
-        HIPCHK(hipMemsetAsync(d->Qx, 0, (size_t)n * 8, d->stream));
-        if (m) HIPCHK(hipMemsetAsync(d->Ax, 0, (size_t)m * 8, d->stream));
-    }
-    if (y_ws && m) {
-        HIPCHK(hipMemcpyAsync(d->tmp_m, y_ws, (size_t)m * 8, hipMemcpyHostToDevice, d->stream));
-        LAUNCH(k_ws_y, vgrid(m), m, d->scaled, d->sc_c, d->tmp_m, d->Einv, d->y, d->ybar);
-        { int rc2 = spmv_At(d, d->y, EpiStore{d->Aty}, false); if (rc2) return rc2; }
-    } else {
-        if (m) { HIPCHK(hipMemsetAsync(d->y, 0, (size_t)m * 8, d->stream)); HIPCHK(hipMemsetAsync(d->ybar, 0, (size_t)m * 8, d->stream)); }
-        HIPCHK(hipMemsetAsync(d->Aty, 0, (size_t)n * 8, d->stream));
-    }
-    const int g = vgrid(n);
-    LAUNCH(k_dots_f, g, n, d->x, d->Qx, d->q, d->part + P_F1 * PGRID, d->part + P_F2 * PGRID);
-    LAUNCH(k_init_mu, vgrid(m), m, d->part + P_F1 * PGRID, d->part + P_F2 * PGRID, g, d->Ax, d->l, d->u, d->mu, d->isq);
-    HIPCHK(hipStreamSynchronize(d->stream));   // x_ws / y_ws host buffers may be released by the caller
-    return 0;
-}
-int qdev_begin_solve(QpdoDev *d) {
-    HIPCHK(hipSetDevice(d->device));
-    d->last_jacobi_iters = 0; d->schur_off = 0; d->schur_strikes = 0;
-    if (d->m) HIPCHK(hipMemsetAsync(d->active_old, 0, (size_t)d->m * sizeof(int), d->stream));
-    return 0;
-}
-
-// ---- residual pass ---------------------------------------------------------------------------------
-int qdev_residuals(QpdoDev *d, int proximal, double sigma, QdevResid *out) {
-    HIPCHK(hipSetDevice(d->device));
-    const int n = d->n, m = d->m;
-    LAUNCH(k_ctrl_clear_pass, 1, d->ctrl);
-    LAUNCH(k_resid_m, vgrid(m), m, d->scaled, d->sc_cinv, d->Ax, d->y, d->ybar, d->mu, d->l, d->u, d->E, d->Einv, d->res_prim, d->w,
-           d->res_prim_in, d->active, d->active_old, d->ctrl);
-    LAUNCH(k_resid_n, vgrid(n), n, d->scaled, proximal, sigma, d->Qx, d->q, d->x, d->xbar, d->Aty, d->Dinv, d->df, d->res_dual,
-           d->res_dual_in, d->ctrl);
-    int rc = read_ctrl(d); if (rc) return rc;
-    const Ctrl *c = d->hctrl;
-    out->res_prim = nrm_of(c, N_PRIM);
-    out->res_prim_in = nrm_of(c, N_PRIM_IN);
-    out->res_dual = nrm_of(c, N_DUAL);
-    out->res_dual_in = nrm_of(c, N_DUAL_IN);
-    if (d->scaled) { out->res_dual *= d->sc_cinv; out->res_dual_in *= d->sc_cinv; }   // termination.c:45,72
-    out->n_active = c->cnt[C_ACTIVE]; out->n_enter = c->cnt[C_ENTER]; out->n_leave = c->cnt[C_LEAVE];
-    return 0;
-}
-
-// ---- linear solve -----------------------------------------------------------------------------------
-// Build the compact index space of this Newton pass: k weighted rows, A_c (k x n) copied out of CSR(A),
-// A_c' (n x k) compacted out of CSR(A') with renumbered columns, d_c.  ~4 passes over A, once per Newton pass.
-static int build_compact(QpdoDev *d) {
-    const int n = d->n, m = d->mloc;                 // local rows; dl = their weights
-    const double *dl = d->d + d->m0;
-    d->kact = 0;
-    if (m == 0) return 0;
-    hipLaunchKernelGGL(k_flag_scan, dim3(1), dim3(1024), 0, d->stream, m, dl, d->cidx, d->rowlist, d->kcount);
-    int k = 0;
-    HIPCHK(hipMemcpyAsync(&k, d->kcount, sizeof(int), hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    if (k <= 0) return 0;
-    // A_c: rows
-    LAUNCH(k_gather_rowinfo, vgrid(k), k, (const int *)d->rowlist, d->Ar.rp, dl, d->row_cnt, d->dc);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d->stream, d->row_cnt, k, d->Arc.rp);
-    LAUNCH(k_copy_rows, 2048, k, (const int *)d->rowlist, d->Ar.rp, d->Ar.ci, (const unsigned short *)d->Ar.ci16, d->Ar.val,
-           (const int *)d->Arc.rp, d->Arc.ci, d->Arc.ci16, d->Arc.val);
-    DevCsr &R = d->Arc;
-    R.nrows = k; R.ncols = n; R.tpr = d->Ar.tpr; R.use_slab = d->Ar.use_slab && k >= 4096;
-    if (R.use_slab) {
-        R.nslabs = d->Ar.nslabs; R.W = d->Ar.W;
-        R.rows_per_wg = (k + 255) / 256; R.slab_grid = (k + R.rows_per_wg - 1) / R.rows_per_wg;
-        LAUNCH(k_build_slab_ptr, vgrid(k), k, R.rp, R.ci, R.nslabs, R.W, R.sp, &d->kcount[1]);
-    }
-    // A_c': columns, renumbered
-    DevCsr &T = d->Atc;
-    const DevCsr &M = d->At;
-    T.nrows = n; T.ncols = k; T.tpr = M.tpr; T.use_slab = M.use_slab && k >= 1024;
-    int W16 = 0;
-    if (T.use_slab) {
-        T.rows_per_wg = M.rows_per_wg; T.slab_grid = M.slab_grid;
-        int nslabs = (k + d->lds_doubles_At - 1) / d->lds_doubles_At; if (nslabs < 1) nslabs = 1;
-        int W = ((k + nslabs - 1) / nslabs + 63) & ~63;
-        if (W > d->lds_doubles_At) { nslabs++; W = ((k + nslabs - 1) / nslabs + 63) & ~63; }
-        if (nslabs > M.nslabs) { nslabs = M.nslabs; W = M.W; }           // never more slabs than the sp table holds
-        T.nslabs = nslabs; T.W = W;
-        if (T.ci16 && W < 65536) W16 = W;
-    }
-    const int g = M.use_slab ? 2048 : spmv_grid(M, M.tpr, false);
-    DISPATCH_TPR(M, k_count_flagged, g, n, M.rp, M.ci, dl, d->row_cnt);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d->stream, d->row_cnt, n, T.rp);
-    LAUNCH(k_compact_rows, 2048, n, M.rp, M.ci, M.val, dl, (const int *)T.rp, T.ci, T.val, (const int *)d->cidx, W16,
-           M.ci16 ? d->Atc.ci16 : (unsigned short *)nullptr);
-    DevCsr Tsave = T;     // (keep pointer to allocated ci16 even when this pass cannot use it)
-    if (T.use_slab) LAUNCH(k_build_slab_ptr, vgrid(n), n, T.rp, T.ci, T.nslabs, T.W, T.sp, &d->kcount[1]);
-    int nn[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(&nn[0], d->Arc.rp + k, sizeof(int), hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipMemcpyAsync(&nn[1], T.rp + n, sizeof(int), hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    R.nnz = nn[0]; T.nnz = nn[1];
-    R.sm_dirty = 1; T.sm_dirty = 1;
-    (void)Tsave;
-    d->kact = k;
-    return 0;
-}
-// choose the heavy rows of this pass (in the compact space) and build P, A_h', S^-1.  Sets d->defl_r.
-static int defl_build(QpdoDev *d) {
-    const int n = d->n, k = d->kact;
-    d->defl_r = 0;
-    if (!d->deflate || k <= 4 * DEFL_MAX) return 0;   // few weighted rows: plain Jacobi-PCG ends within ~n iterations anyway
-    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
-    LAUNCH(k_absmax_mul, vgrid(k), k, (const double *)d->dc, (const double *)nullptr, d->ctrl, N_A);
-    HIPCHK(hipMemsetAsync(d->defl_hist, 0, 32 * sizeof(int), d->stream));
-    LAUNCH(k_defl_hist, vgrid(k), k, (const double *)d->dc, (const Ctrl *)d->ctrl, d->defl_hist);
-    int hist[32];
-    HIPCHK(hipMemcpyAsync(hist, d->defl_hist, sizeof(hist), hipMemcpyDeviceToHost, d->stream));
-    int rc = read_ctrl(d); if (rc) return rc;
-    const double dmax = nrm_of(d->hctrl, N_A);
-    if (!(dmax > 0.0)) return 0;
-    static const bool dbg = getenv("QPDO_DEFL_DEBUG") != nullptr;
-    if (dbg) { fprintf(stderr, "[defl] k=%d dmax=%.3e sigma_f=%.3e hist:", k, dmax, d->sigma_f); for (int b = 0; b < 32; b++) fprintf(stderr, " %d", hist[b]); fprintf(stderr, "\n"); }
-    // largest bucket index kb whose cumulative count still fits; rows in buckets 0..kb are > dmax / 2^(kb+1)
-    int cum = 0, kb = -1;
-    for (int b = 0; b < 32; b++) { if (cum + hist[b] > DEFL_MAX) break; cum += hist[b]; kb = b; }
-    if (kb < 2 || cum == 0) return 0;              // no group of <= 64 rows stands out by a factor of 8: nothing to deflate
-    const double thr = dmax * ldexp(1.0, -(kb + 1));
-    hipLaunchKernelGGL(k_defl_select, dim3(1), dim3(1024), 0, d->stream, k, (const double *)d->dc, thr, d->defl_flag, d->tmp_m, d->defl_list, d->defl_count);
-    int r = 0;
-    HIPCHK(hipMemcpyAsync(&r, d->defl_count, sizeof(int), hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    if (r <= 0 || r > DEFL_MAX) return 0;
-    const DevCsr &T = d->Atc;
-    // P: Jacobi diagonal of the remainder (floored), A_h': the heavy columns of A_c'
-    const int gAt = d->At.use_slab ? 2048 : spmv_grid(d->At, d->At.tpr, false);
-    DISPATCH_TPR(d->At, k_jacobi_diag2, gAt, n, T.rp, T.ci, T.val, (const double *)d->tmp_m, (const double *)d->dc, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
-    DISPATCH_TPR(d->At, k_count_flagged, gAt, n, T.rp, T.ci, (const double *)d->defl_flag, d->row_cnt);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d->stream, d->row_cnt, n, d->Ath.rp);
-    LAUNCH(k_compact_rows, 2048, n, T.rp, T.ci, T.val, (const double *)d->defl_flag, (const int *)d->Ath.rp, d->Ath.ci, d->Ath.val,
-           (const int *)nullptr, 0, (unsigned short *)nullptr);
-    d->Ath.nrows = n; d->Ath.ncols = k; d->Ath.tpr = 4; d->Ath.use_slab = 0; d->Ath.nnz = (long long)r * d->max_row_nnz_A;
-    HIPCHK(hipMemsetAsync(d->defl_t, 0, (size_t)k * 8, d->stream));
-    // S and its inverse (host, r <= 64)
-    hipLaunchKernelGGL(k_defl_S, dim3(r, r), dim3(64), 0, d->stream, r, (const int *)d->defl_list, d->Arc.rp, d->Arc.ci, d->Arc.val,
-                       (const double *)d->pc_diag, (const double *)d->dc, d->defl_S);
-    static thread_local std::vector<double> Sv, Lv, Liv, Siv;
-    Sv.assign((size_t)DEFL_MAX * DEFL_MAX, 0.0); Lv.assign((size_t)DEFL_MAX * DEFL_MAX, 0.0); Liv.assign((size_t)DEFL_MAX * DEFL_MAX, 0.0); Siv.assign((size_t)DEFL_MAX * DEFL_MAX, 0.0);
-    double *S = Sv.data(), *L = Lv.data(), *Li = Liv.data(), *Si = Siv.data();
-    HIPCHK(hipMemcpyAsync(S, d->defl_S, (size_t)DEFL_MAX * DEFL_MAX * 8, hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    const int N = DEFL_MAX;
-    for (int i = 0; i < r; i++)                     // Cholesky S = L L'
-        for (int j = 0; j <= i; j++) {
-            double t = S[i * N + j];
-            for (int q = 0; q < j; q++) t -= L[i * N + q] * L[j * N + q];
-            if (i == j) { if (!(t > 0.0)) return 0; L[i * N + i] = sqrt(t); }
-            else L[i * N + j] = t / L[j * N + j];
-        }
-    for (int c = 0; c < r; c++)                     // Li = L^-1 (lower)
-        for (int i = 0; i < r; i++) {
-            if (i < c) { Li[i * N + c] = 0.0; continue; }
-            double t = (i == c) ? 1.0 : 0.0;
-            for (int q = c; q < i; q++) t -= L[i * N + q] * Li[q * N + c];
-            Li[i * N + c] = t / L[i * N + i];
-        }
-    for (int i = 0; i < r; i++)                     // S^-1 = Li' Li
-        for (int j = 0; j <= i; j++) {
-            double t = 0.0;
-            for (int q = i; q < r; q++) t += Li[q * N + i] * Li[q * N + j];
-            Si[i * N + j] = t; Si[j * N + i] = t;
-        }
-    HIPCHK(hipMemcpyAsync(d->defl_Sinv, Si, (size_t)DEFL_MAX * DEFL_MAX * 8, hipMemcpyHostToDevice, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    d->defl_r = r;
-    d->defl_passes++;
-    return 0;
-}
-// z <- M^-1 r given u = P^-1 r in z; leaves the r.z partials in p_rz.  Returns their count.
-static int defl_apply(QpdoDev *d, const int *done, double *p_rz) {
-    const int r = d->defl_r;
-    hipLaunchKernelGGL(k_defl_v, dim3(r), dim3(64), 0, d->stream, done, r, (const int *)d->defl_list, d->Arc.rp, d->Arc.ci, d->Arc.val,
-                       (const double *)d->pc_z, d->defl_v);
-    hipLaunchKernelGGL(k_defl_w, dim3(1), dim3(DEFL_MAX), 0, d->stream, done, r, (const double *)d->defl_Sinv, (const double *)d->defl_v,
-                       (const int *)d->defl_list, d->defl_t);
-    EpiDeflZ e{d->pc_diag, d->pc_r, d->pc_z, p_rz};
-    if (done) launch_spmv_pcg(d, d->Ath, d->defl_t, e, true);
-    else launch_spmv(d, d->Ath, d->defl_t, e, true);
-    d->st.spmv_calls--; d->st.spmv_bytes -= (int64_t)d->Ath.alg_bytes();     // not one of the big products
-    return spmv_pgrid(d->Ath);
-}
-// ---- Schur-complement mode of the PCG ---------------------------------------------------------------------
-// Late in a solve the weights d = 1/mu of the active rows spread over 2^8..2^16 and Jacobi-PCG on
-// K = Q~ + A_c' D A_c needs 1000+ iterations per pass (kappa ~ spread x the Marchenko-Pastur ratio of A_c).
-// Preconditioner M = Dq + A_c' D A_c with Dq = diag(Q~): it treats the whole penalty term exactly, so M^-1 K =
-// I + M^-1 offdiag(Q) and the outer CG converges in ~10 iterations when Q is diagonally dominant in the spectral
-// sense.  M^-1 r = u - Dq^-1 A_c' s,  u = Dq^-1 r,  S' s = A_c u,  S' = D^-1 + A_c Dq^-1 A_c'  (k x k, never formed):
-// the inner system is solved by Jacobi-PCG; its conditioning is that of A_c Dq^-1 A_c' (Marchenko-Pastur,
-// ((1+sqrt(k/n))/(1-sqrt(k/n)))^2 ~ 160 at k/n = 0.73) and does NOT depend on the spread of d; its products are two
-// SpMV with the compact matrices and no Q product.  Measured on the C2 system of the last pass (numpy prototype):
-// 1862 Jacobi iterations (5586 SpMV) -> 11 outer x 78 inner (1777 SpMV, none of them Q).  The inner solve must be
-// tight (1e-6): at 1e-3 the outer iteration degrades to hundreds of steps even with a flexible beta.
-// Used when 256 <= k <= 0.8 n (beyond that ratio the inner conditioning explodes); falls back to the deflated
-// Jacobi-PCG below when the outer iteration does not converge within SCHUR_OUTER_MAXIT steps (twice: off for the solve).
-static int read_ctrl2(QpdoDev *d) {
-    HIPCHK(hipMemcpyAsync(d->hctrl2, d->ctrl2, sizeof(Ctrl), hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    return 0;
-}
-static const int SCHUR_INNER_MAXIT = 4000, SCHUR_OUTER_MAXIT = 40;
-// s_x = S'^-1 s_v by Jacobi-PCG (device latch in ctrl2, batches of iterations between host syncs)
-static int schur_inner_solve(QpdoDev *d, double tol, int *iters) {
-    const int k = d->kact, g = vgrid(k);
-    double *P2 = d->part2;                   // slots: 0 p.Sp, 1 r.z, 2 r.r
-    const int *done2 = &d->ctrl2->cnt[C_PCG_DONE];
-    LAUNCH(k_pcg_init, g, k, (const double *)d->s_v, (const double *)d->s_diag, d->s_x, d->s_r, d->s_z, d->s_p, P2 + 1 * PGRID, P2 + 2 * PGRID);
-    LAUNCH(k_pcg_init2, 1, (const double *)(P2 + 1 * PGRID), g, (const double *)(P2 + 2 * PGRID), g, d->ctrl2);
-    const int pcnt = spmv_pgrid(d->Arc);
-    int it = 0;
-    // Batches between host syncs.  The iteration count of an inner solve is almost the same as that of the previous one
-    // in the pass (same operator, same tolerance), so the first batch runs to just short of it and the rest are short:
-    // few syncs and few latched (no-op) launches after convergence.
-    int batch = d->schur_last_inner > 12 ? d->schur_last_inner - 6 : d->pcg_batch;
-    while (it < SCHUR_INNER_MAXIT) {
-        const int it_before = it, sample_b = batch / 2;
-        for (int b = 0; b < batch; b++) {
-            const bool f32 = d->inner_f32 && d->Atc.use_slab && d->Arc.use_slab && d->Atc.vsm32 && d->Arc.vsm32 && d->Atc.i16sm && d->Arc.i16sm;
-            if (f32) launch_spmv_slab32(d, d->Atc, d->s_p, EpiDivStore{d->pc_diag, d->tmp_n}, done2);
-            else launch_spmv_pcg(d, d->Atc, d->s_p, EpiDivStore{d->pc_diag, d->tmp_n}, false, done2);
-            // HIP-event sample of the dominant kernel, one per batch, taken mid-batch (the first launches after a host
-            // sync run on an idle GPU and would bias the sample)
-            if (b == sample_b) (void)hipEventRecord(d->ev0, d->stream);
-            if (f32) launch_spmv_slab32(d, d->Arc, d->tmp_n, EpiSchurA{d->dc, d->s_p, d->s_Sp, P2}, done2);
-            else launch_spmv_pcg(d, d->Arc, d->tmp_n, EpiSchurA{d->dc, d->s_p, d->s_Sp, P2}, true, done2);
-            if (b == sample_b) (void)hipEventRecord(d->ev1, d->stream);
-            LAUNCH(k_pcg_update, g, k, (const Ctrl *)d->ctrl2, (const double *)P2, pcnt, (const double *)d->s_p, (const double *)d->s_Sp,
-                   (const double *)d->s_diag, d->s_x, d->s_r, d->s_z, P2 + 1 * PGRID, P2 + 2 * PGRID);
-            LAUNCH(k_pcg_scalar, 1, d->ctrl2, (const double *)(P2 + 1 * PGRID), g, (const double *)(P2 + 2 * PGRID), g, tol);
-            LAUNCH(k_pcg_p, g, k, (const Ctrl *)d->ctrl2, (const double *)d->s_z, d->s_p);
-        }
-        it += batch;
-        int rc = read_ctrl2(d); if (rc) return rc;
-        if (d->hctrl2->cnt[C_PCG_IT] > it_before + sample_b) {          // the sampled iteration of this batch really ran
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, d->ev0, d->ev1) == hipSuccess) { d->ev_ac_ms += ms; d->ev_ac_bytes += d->Arc.alg_bytes(); d->ev_ac_n++; }
-        }
-        if (d->hctrl2->cnt[C_PCG_DONE]) break;
-        batch = 4;
-    }
-    d->schur_last_inner = d->hctrl2->cnt[C_PCG_IT];
-    *iters = d->hctrl2->cnt[C_PCG_IT];
-    return d->hctrl2->cnt[C_PCG_DONE] ? 0 : 1;          // 1: not converged
-}
-// z <- M^-1 r given u = Dq^-1 r in pc_z; leaves the r.z partials in p_rz.  Returns their count (or -1 on failure).
-static int schur_apply(QpdoDev *d, double tol, double *p_rz, int *inner_iters, int *status) {
-    launch_spmv(d, d->Arc, d->pc_z, EpiStore{d->s_v}, false);
-    int it = 0;
-    *status = schur_inner_solve(d, tol, &it);
-    *inner_iters += it;
-    if (*status < 0) return -1;
-    launch_spmv(d, d->Atc, d->s_x, EpiDeflZ{d->pc_diag, d->pc_r, d->pc_z, p_rz}, true);
-    return spmv_pgrid(d->Atc);
-}
-// K dx = rhs with the Schur-preconditioned outer CG.  *fallback = 1: did not converge, the caller reruns Jacobi-PCG.
-static int pcg_schur_solve(QpdoDev *d, int *iters_out, int *fallback) {
-    const int n = d->n, k = d->kact, g = vgrid(n);
-    double *P = d->part;
-    *fallback = 0;
-    LAUNCH(k_axpy_const, g, n, (const double *)d->qdiag, d->sigma_f, d->pc_diag);                  // Dq
-    DISPATCH_TPR(d->Ar, k_schur_diag, (d->Ar.use_slab ? 2048 : spmv_grid(d->Ar, d->Ar.tpr, false)), k, d->Arc.rp, d->Arc.ci, d->Arc.val,
-                 (const double *)d->pc_diag, (const double *)d->dc, d->s_diag);
-    // Inner tolerance.  An inner residual rho leaves M z - r = A_c' D rho: the error that matters is weighted by D, so
-    // the tolerance must shrink with the largest weight (tau = 1e-6 sufficed on every C4 pass with dmax <= 5e3 and
-    // failed at dmax = 7e5).  It is also tightened on the fly whenever an outer step reduces the residual by less than 4x.
-    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
-    LAUNCH(k_absmax_mul, vgrid(k), k, (const double *)d->dc, (const double *)nullptr, d->ctrl, N_A);
-    LAUNCH(k_pcg_init, g, n, d->rhs, d->pc_diag, d->dx, d->pc_r, d->pc_z, d->pc_p, P + P_RZ * PGRID, P + P_RR * PGRID);
-    { int rc0 = read_ctrl(d); if (rc0) return rc0; }
-    const double dmax = nrm_of(d->hctrl, N_A);
-    d->schur_last_inner = 0;
-    double tau = 1e-6 * (dmax > 1e4 ? 1e4 / dmax : 1.0);
-    if (tau < 1e-13) tau = 1e-13;
-    int inner = 0, st = 0;
-    int cnt_rz = schur_apply(d, tau, P + P_RZ * PGRID, &inner, &st);
-    if (cnt_rz < 0) return -1;
-    if (st) { *fallback = 1; return 0; }
-    LAUNCH(k_copy, g, n, (const double *)d->pc_z, d->pc_p);
-    LAUNCH(k_pcg_init2, 1, P + P_RZ * PGRID, cnt_rz, P + P_RR * PGRID, g, d->ctrl);
-    const int pKp_cnt = spmv_pgrid(d->Atc);
-    int outer = 0;
-    double prev_rn = -1.0;
-    for (;;) {
-        int rc = read_ctrl(d); if (rc) return rc;
-        if (d->hctrl->cnt[C_PCG_DONE]) break;
-        if (outer > 0) {
-            const double rn = d->hctrl->val[V_RNORM];
-            if (prev_rn > 0.0 && rn > 0.25 * prev_rn && tau > 1e-13) { tau *= 1e-2; if (tau < 1e-13) tau = 1e-13; }
-            prev_rn = rn;
-        }
-        if (outer >= SCHUR_OUTER_MAXIT) { if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[schur] k=%d outer cap reached (inner=%d)\n", k, inner); *fallback = 1; return 0; }
-        launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
-        launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQ{d->pc_p, d->sigma_f, d->pc_Kp}, false);
-        launch_spmv_pcg(d, d->Atc, d->tc, EpiPcgAt{d->pc_p, d->pc_Kp, P + P_PKP * PGRID}, true);
-        LAUNCH(k_pcg_update, g, n, (const Ctrl *)d->ctrl, (const double *)(P + P_PKP * PGRID), pKp_cnt, (const double *)d->pc_p, (const double *)d->pc_Kp,
-               (const double *)d->pc_diag, d->dx, d->pc_r, d->pc_z, P + P_RZ * PGRID, P + P_RR * PGRID);
-        cnt_rz = schur_apply(d, tau, P + P_RZ * PGRID, &inner, &st);
-        if (cnt_rz < 0) return -1;
-        if (st) { if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[schur] k=%d inner solve did not converge (outer=%d inner=%d)\n", k, outer, inner); *fallback = 1; return 0; }
-        LAUNCH(k_pcg_scalar, 1, d->ctrl, (const double *)(P + P_RZ * PGRID), cnt_rz, (const double *)(P + P_RR * PGRID), g, d->pcg_tol);
-        LAUNCH(k_pcg_p, g, n, (const Ctrl *)d->ctrl, (const double *)d->pc_z, d->pc_p);
-        outer++;
-    }
-    if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[schur] dmax=%.2e tau_end=%.1e ", dmax, tau);
-    *iters_out = outer + inner;
-    d->schur_passes++;
-    // converged, but slowly: Q is far from its diagonal in the spectral sense and every outer step pays a full inner solve --
-    // the deflated Jacobi-PCG is the better solver for such a Q (two slow passes switch the mode off for the solve)
-    if (outer > 20 && ++d->schur_strikes >= 2) d->schur_off = 1;
-    if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[schur] k=%d outer=%d inner=%d\n", k, outer, inner);
-    return 0;
-}
-static int pcg_solve(QpdoDev *d, int *iters_out) {
-    const int n = d->n;
-    if (!d->qdiag_valid) {
-        LAUNCH(k_extract_diag, vgrid(n), n, d->Qf.rp, d->Qf.ci, d->Qf.val, d->qdiag);
-        d->qdiag_valid = 1;
-    }
-    int rc = build_compact(d); if (rc) return rc;
-    const int k = d->kact;
-    {   // Schur-complement mode whenever its inner system is well conditioned (k/n <= 0.8) and worth the set-up (k >= 256);
-        // it also wins on the early passes (uniform weights): fewer products and almost none of them with Q
-        // (C4: 9.2 s when used only after a slow Jacobi pass, 8.8 s when used from the first pass on)
-        const bool allowed = d->comm.world == 1 && !d->schur_off && d->schur_mode != 0 && k >= 256 && (double)k <= 0.8 * (double)n;
-        if (allowed) {
-            int fb = 0;
-            rc = pcg_schur_solve(d, iters_out, &fb); if (rc) return rc;
-            if (!fb) return 0;
-            if (++d->schur_strikes >= 2) d->schur_off = 1;      // did not converge twice: plain path from here on
-        }
-    }
-    rc = defl_build(d); if (rc) return rc;
-    const bool defl = d->defl_r > 0;
-    const bool dist = d->comm.world > 1;
-    if (!defl && dist) {   // sum_i A_ij^2 d_i over the local rows, summed over ranks, plus Q_jj + sigma_f
-        if (k > 0) {
-            const int gAt = d->At.use_slab ? 2048 : spmv_grid(d->At, d->At.tpr, false);
-            DISPATCH_TPR(d->At, k_jacobi_diag, gAt, n, d->Atc.rp, d->Atc.ci, d->Atc.val, (const double *)d->dc, (const double *)d->zeros_n, 0.0, d->dist_tmp);
-        } else HIPCHK(hipMemsetAsync(d->dist_tmp, 0, (size_t)n * 8, d->stream));
-        rc = comm_allreduce(d, d->dist_tmp, (size_t)n, 0); if (rc) return rc;
-        LAUNCH(k_add3, vgrid(n), n, (const double *)d->dist_tmp, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
-    } else if (!defl) {   // Jacobi diagonal: Q_jj + sigma_f + sum_i A_ij^2 d_i
-        if (k > 0) {
-            const int gAt = d->At.use_slab ? 2048 : spmv_grid(d->At, d->At.tpr, false);
-            DISPATCH_TPR(d->At, k_jacobi_diag, gAt, n, d->Atc.rp, d->Atc.ci, d->Atc.val, (const double *)d->dc, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
-        } else {
-            LAUNCH(k_axpy_const, vgrid(n), n, (const double *)d->qdiag, d->sigma_f, d->pc_diag);
-        }
-    }
-    const int g = vgrid(n);
-    double *P = d->part;
-    const int *done = &d->ctrl->cnt[C_PCG_DONE];
-    LAUNCH(k_pcg_init, g, n, d->rhs, d->pc_diag, d->dx, d->pc_r, d->pc_z, d->pc_p, P + P_RZ * PGRID, P + P_RR * PGRID);
-    int cnt_rz = g;
-    if (defl) {
-        cnt_rz = defl_apply(d, nullptr, P + P_RZ * PGRID);
-        LAUNCH(k_copy, g, n, (const double *)d->pc_z, d->pc_p);
-    }
-    LAUNCH(k_pcg_init2, 1, P + P_RZ * PGRID, cnt_rz, P + P_RR * PGRID, g, d->ctrl);
-    const int pKp_cnt = dist ? vgrid(n) : (k > 0 ? spmv_pgrid(d->Atc) : spmv_pgrid(d->Qf));
-    // one PCG iteration as a sequence of launches on the backend stream
-    auto issue_iteration = [&](bool sample) -> int {
-        if (dist) {
-            // K p = sigma_f p + sum over ranks of ( Q_rows p  [rows n0..]  +  A_c,loc' (d_c .* A_c,loc p) )
-            HIPCHK(hipMemsetAsync(d->Kp_part, 0, (size_t)n * 8, d->stream));
-            if (k > 0) launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
-            if (sample) (void)hipEventRecord(d->ev0, d->stream);
-            if (d->nloc > 0) launch_spmv_pcg(d, d->Qs, d->pc_p, EpiAddTo{d->Kp_part, d->n0}, false);
-            if (sample) (void)hipEventRecord(d->ev1, d->stream);
-            if (k > 0) launch_spmv_pcg(d, d->Atc, d->tc, EpiAddTo{d->Kp_part, 0}, false);
-            int rcx = comm_allreduce(d, d->Kp_part, (size_t)n, 0); if (rcx) return rcx;
-            hipLaunchKernelGGL(k_pcg_dist_finish, dim3(g), dim3(BLK), 0, d->stream, n, done, (const double *)d->Kp_part, (const double *)d->pc_p,
-                               d->sigma_f, d->pc_Kp, P + P_PKP * PGRID);
-        } else if (k > 0) {
-            launch_spmv_pcg(d, d->Arc, d->pc_p, EpiPcgA{d->dc, d->tc, nullptr}, false);
-            if (sample) (void)hipEventRecord(d->ev0, d->stream);
-            launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQ{d->pc_p, d->sigma_f, d->pc_Kp}, false);
-            if (sample) (void)hipEventRecord(d->ev1, d->stream);
-            launch_spmv_pcg(d, d->Atc, d->tc, EpiPcgAt{d->pc_p, d->pc_Kp, P + P_PKP * PGRID}, true);
-        } else {
-            if (sample) (void)hipEventRecord(d->ev0, d->stream);
-            launch_spmv_pcg(d, d->Qf, d->pc_p, EpiPcgQdot{d->pc_p, d->sigma_f, d->pc_Kp, P + P_PKP * PGRID}, true);
-            if (sample) (void)hipEventRecord(d->ev1, d->stream);
-        }
-        LAUNCH(k_pcg_update, g, n, d->ctrl, P + P_PKP * PGRID, pKp_cnt, d->pc_p, d->pc_Kp, d->pc_diag, d->dx, d->pc_r, d->pc_z,
-               P + P_RZ * PGRID, P + P_RR * PGRID);
-        if (defl) defl_apply(d, done, P + P_RZ * PGRID);
-        LAUNCH(k_pcg_scalar, 1, d->ctrl, P + P_RZ * PGRID, cnt_rz, P + P_RR * PGRID, g, d->pcg_tol);
-        LAUNCH(k_pcg_p, g, n, d->ctrl, d->pc_z, d->pc_p);
-        return 0;
-    };
-    // Launch-bound regime (cache-resident matrices): replay a captured batch of iterations as a hipGraph.  The
-    // kernels leave immediately once the device-side latch is set, so replaying whole batches stays exact.
-    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
-    const bool use_graph = d->pcg_graph && !dist && !d->Qf.use_slab && d->pcg_maxit >= d->pcg_batch;
-    if (use_graph) {
-        bool ok = hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        if (ok) {
-            for (int b = 0; b < d->pcg_batch && ok; b++) ok = issue_iteration(false) == 0;
-            hipError_t e = hipStreamEndCapture(d->stream, &graph);
-            ok = ok && e == hipSuccess && graph;
-        }
-        if (ok) ok = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
-        if (!ok) { if (graph) (void)hipGraphDestroy(graph); graph = nullptr; gexec = nullptr; (void)hipGetLastError(); }
-    }
-    int it = 0;
-    rc = 0;
-    while (it < d->pcg_maxit) {
-        const int it_before = it;
-        int batch = d->pcg_batch; if (it + batch > d->pcg_maxit) batch = d->pcg_maxit - it;
-        if (gexec && batch == d->pcg_batch) {
-            hipError_t e = hipGraphLaunch(gexec, d->stream);
-            if (e != hipSuccess) { rc = set_err(e, "hipGraphLaunch", __LINE__); break; }
-            d->st.spmv_calls += (k > 0 ? 3 : 1) * (batch - 1);      // issue_iteration counted one batch during capture
-        } else {
-            for (int b = 0; b < batch && !rc; b++) rc = issue_iteration(b == 0 && !gexec);
-            if (rc) break;
-        }
-        it += batch;
-        rc = read_ctrl(d); if (rc) break;
-        if (!gexec && d->hctrl->cnt[C_PCG_IT] > it_before) {      // the sampled (first) iteration of this batch really ran
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, d->ev0, d->ev1) == hipSuccess) { d->ev_spmv_ms += ms; d->ev_spmv_n++; }
-        }
-        if (d->hctrl->cnt[C_PCG_DONE]) break;
-    }
-    if (gexec) (void)hipGraphExecDestroy(gexec);
-    if (graph) (void)hipGraphDestroy(graph);
-    if (rc) return rc;
-    *iters_out = d->hctrl->cnt[C_PCG_IT];
-    d->last_jacobi_iters = *iters_out;
-    if (getenv("QPDO_DEFL_DEBUG")) fprintf(stderr, "[pcg] k=%d defl_r=%d iters=%d\n", k, d->defl_r, *iters_out);
-    return 0;
-}
-
-// ---- dense direct solve ------------------------------------------------------------------------------
-static const int DOUTER = 4;          // inner 64-blocks per outer panel (256 columns)
-static int dense_alloc(QpdoDev *d) {
-    if (d->Kd) return 0;
-    const int ld = (d->n + DNB - 1) / DNB * DNB;
-    d->dense_ld = ld; d->dense_nblk = ld / DNB;
-    int rc = dev_alloc(d, &d->Kd, (size_t)ld * ld);
-    if (!rc) rc = dev_alloc(d, &d->Wd, (size_t)2 * ld * DNB * DOUTER);     // two outer panels of W = L D (look-ahead)
-    if (!rc && !d->stream2) {
-        // The trailing updates would fill every CU and starve the one-workgroup diagonal kernel of the next panel
-        // (it needs 66 KB of LDS on one CU), so their stream leaves a few CUs out of its mask.
-        int reserve = 32;
-        if (const char *rs = getenv("QPDO_DENSE_RESERVE_CUS")) reserve = atoi(rs);
-        hipDeviceProp_t prop; int ncu = 256;
-        if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        hipError_t e = hipErrorInvalidValue;
-        if (reserve > 0 && reserve < ncu) {
-            const int words = (ncu + 31) / 32;
-            std::vector<uint32_t> mask((size_t)words, 0u);
-            for (int c = 0; c < ncu - reserve; c++) mask[c >> 5] |= 1u << (c & 31);
-            e = hipExtStreamCreateWithCUMask(&d->stream2, (uint32_t)words, mask.data());
-            if (e != hipSuccess) { (void)hipGetLastError(); d->stream2 = nullptr; }
-        }
-        if (e != hipSuccess) e = hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking);
-        for (int i = 0; i < 2 && e == hipSuccess; i++) { e = hipEventCreateWithFlags(&d->evF[i], hipEventDisableTiming); if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evB[i], hipEventDisableTiming); }
-        if (e != hipSuccess) rc = set_err(e, "dense look-ahead stream", __LINE__);
-    }
-    if (!rc) rc = dev_alloc(d, &d->Dg, (size_t)ld);
-    if (!rc) rc = dev_alloc(d, &d->Linv, (size_t)d->dense_nblk * DNB * DNB);
-    if (!rc && d->wb_enable) {
-        const size_t mm = d->m > 0 ? (size_t)d->m : 1;
-        rc = dev_alloc(d, &d->d_fact, mm);
-        if (!rc) rc = dev_alloc(d, &d->wb_Z, (size_t)ld * (WB_MAX + 16));      // + one padding group of right-hand sides
-        if (!rc) rc = dev_alloc(d, &d->wb_T, (size_t)ld * (WB_MAX + 16));
-        if (!rc) rc = dev_alloc(d, &d->wb_G, (size_t)WB_MAX * WB_MAX);
-        if (!rc) rc = dev_alloc(d, &d->wb_v, (size_t)WB_MAX);
-        if (!rc) rc = dev_alloc(d, &d->wb_w, (size_t)WB_MAX);
-        if (!rc) rc = dev_alloc(d, &d->wb_t, (size_t)WB_MAX + 1);
-        if (!rc) rc = dev_alloc(d, &d->wb_slot, mm);
-        if (!rc) rc = dev_alloc(d, &d->wb_rows, (size_t)WB_MAX);
-        if (!rc) rc = dev_alloc(d, &d->wb_cnt, (size_t)2);
-        if (!rc) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldl_fwd_mr), hipFuncAttributeMaxDynamicSharedMemorySize, (DNB * 80 + WB_MAX * 68) * 8);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldl_bwd_mr), hipFuncAttributeMaxDynamicSharedMemorySize, (DNB * 68 + WB_MAX * 68) * 8);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wb_lu), hipFuncAttributeMaxDynamicSharedMemorySize, WB_MAX * (WB_MAX + 2) * 8);
-            if (e != hipSuccess) rc = set_err(e, "hipFuncSetAttribute", __LINE__);
-        }
-    }
-    if (!rc) rc = dev_alloc(d, &d->dz, (size_t)ld);
-    if (!rc) rc = dev_alloc(d, &d->dxw, (size_t)ld);
-    if (!rc) rc = dev_alloc(d, &d->LinvT, (size_t)d->dense_nblk * DNB * DNB);
-    if (!rc) rc = dev_alloc(d, &d->ch_y, (size_t)ld);
-    if (!rc) rc = dev_alloc(d, &d->ch_x, (size_t)ld);
-    if (!rc) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        if (e != hipSuccess) rc = set_err(e, "hipFuncSetAttribute", __LINE__);
-    }
-    return rc;
-}
-static int dense_factor(QpdoDev *d) {
-    int rc = dense_alloc(d); if (rc) return rc;
-    const int n = d->n, ld = d->dense_ld, nb = d->dense_nblk;
-    const int g = ld < 1024 ? ld : 1024;
-    static const bool kc16 = [] { const char *e = getenv("QPDO_SYRK_KC"); return !(e && atoi(e) == 32); }();
-    static const bool lookahead = [] { const char *e = getenv("QPDO_DENSE_LOOKAHEAD"); return !(e && atoi(e) == 0); }();
-    hipLaunchKernelGGL(k_dense_assemble, dim3(g), dim3(64), (size_t)n * sizeof(double), d->stream, n, ld, d->Qf.rp, d->Qf.ci, d->Qf.val,
-                       d->At.rp, d->At.ci, d->At.val, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)d->d, d->sigma_f, d->Kd);
-    // Outer panel p (DOUTER block columns): F_p = its factorization (a serial diag -> panel -> narrow update chain that
-    // fills few CUs), a_p = trailing update of the NEXT outer panel's columns, b_p = trailing update of everything
-    // beyond.  One-deep look-ahead: F_p, a_p on the main stream, b_p on stream2, so that F_{p+1} overlaps b_p.
-    //   F_p <- a_{p-1};  a_p, b_p <- F_p, b_{p-1};  W_p lives in buffer p&1 (F_{p+1} <- a_p <- b_{p-1}: its reader is done).
-    // Every element of K receives the same updates in the same order as without look-ahead: results are bit-identical.
-    auto syrk = [&](hipStream_t st, const double *W, int kb0, int nkb, int wcol0, int tj_lo, int tj_hi) {
-        const dim3 grid(nb - tj_lo, tj_hi - tj_lo);
-        if (kc16) hipLaunchKernelGGL(k_ldl_syrk<16>, grid, dim3(256), 0, st, d->Kd, ld, W, kb0, nkb, wcol0, tj_lo, tj_hi);
-        else      hipLaunchKernelGGL(k_ldl_syrk<32>, grid, dim3(256), 0, st, d->Kd, ld, W, kb0, nkb, wcol0, tj_lo, tj_hi);
-    };
-    bool b_pending = false;
-    int p = 0;
-    for (int J0 = 0; J0 < nb; J0 += DOUTER, p++) {
-        const int Jend = J0 + DOUTER < nb ? J0 + DOUTER : nb;
-        double *W = d->Wd + (size_t)(p & 1) * ld * DNB * DOUTER;
-        for (int kb = J0; kb < Jend; kb++) {
-            hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(128), 0, d->stream, d->Kd, ld, kb, d->Dg, d->Linv, d->LinvT);
-            const int below = nb - kb - 1;
-            if (below > 0) {
-                hipLaunchKernelGGL(k_ldl_panel, dim3(below), dim3(256), 0, d->stream, d->Kd, ld, kb, kb - J0, (const double *)d->Dg,
-                                   (const double *)d->Linv, W);
-                if (kb + 1 < Jend) syrk(d->stream, W, kb, 1, kb - J0, kb + 1, Jend);      // rest of this outer panel
-            }
-        }
-        if (Jend < nb) {
-            const int Jend2 = (lookahead && Jend + DOUTER < nb) ? Jend + DOUTER : nb;
-            if (Jend2 < nb) {
-                HIPCHK(hipEventRecord(d->evF[p & 1], d->stream));
-                HIPCHK(hipStreamWaitEvent(d->stream2, d->evF[p & 1], 0));
-            }
-            if (b_pending) HIPCHK(hipStreamWaitEvent(d->stream, d->evB[(p - 1) & 1], 0));
-            b_pending = false;
-            syrk(d->stream, W, J0, Jend - J0, 0, Jend, Jend2);                             // a_p
-            if (Jend2 < nb) {
-                syrk(d->stream2, W, J0, Jend - J0, 0, Jend2, nb);                          // b_p
-                HIPCHK(hipEventRecord(d->evB[p & 1], d->stream2));
-                b_pending = true;
-            }
-        }
-    }
-    if (b_pending) HIPCHK(hipStreamWaitEvent(d->stream, d->evB[(p - 1) & 1], 0));
-    HIPCHK(hipGetLastError());
-    d->dense_valid = 1;
-    d->dense_factored = 1; d->dense_fact_sigma = d->sigma_f; d->wb_k = 0;
-    if (d->wb_enable && d->m > 0) {        // the factor belongs to this weight vector; no row holds a low-rank slot
-        HIPCHK(hipMemcpyAsync(d->d_fact, d->d, (size_t)d->m * 8, hipMemcpyDeviceToDevice, d->stream));
-        HIPCHK(hipMemsetAsync(d->wb_slot, 0xFF, (size_t)d->m * sizeof(int), d->stream));
-    }
-    d->st.factor_count++;
-    return 0;
-}
-// z0 = K0^-1 src; the result (ld entries) is at d->dsol
-static int dense_solve_core(QpdoDev *d, const double *src) {
-    const int n = d->n, ld = d->dense_ld, nb = d->dense_nblk;
-    LAUNCH(k_dense_load_rhs, vgrid(ld), n, ld, src, d->dxw);
-    if (d->dense_chain) {          // one launch per direction, block rows chained through polled device-scope loads
-        LAUNCH(k_fill_sentinel, vgrid(ld), ld, d->dz, d->ch_x);
-        LAUNCH(k_ctrl_set_int, 1, d->ctrl, C_CHAIN_ERR, 0);
-        hipLaunchKernelGGL(k_ldl_chain<true>, dim3(nb), dim3(256), 0, d->stream, (const double *)d->Kd, ld, nb, (const double *)d->Linv,
-                           (const double *)d->Dg, (const double *)d->dxw, d->dz, d->ch_y, d->ctrl);
-        hipLaunchKernelGGL(k_ldl_chain<false>, dim3(nb), dim3(256), 0, d->stream, (const double *)d->Kd, ld, nb, (const double *)d->LinvT,
-                           (const double *)d->Dg, (const double *)d->ch_y, d->ch_x, (double *)nullptr, d->ctrl);
-        d->dsol = d->ch_x;
-        return 0;
-    }
-    for (int kb = 0; kb < nb; kb++) {
-        const int below = nb - kb - 1;
-        hipLaunchKernelGGL(k_ldl_fwd, dim3(below > 0 ? below : 1), dim3(64), 0, d->stream, (const double *)d->Kd, ld, kb, (const double *)d->Linv, d->dxw, d->dz);
-    }
-    LAUNCH(k_dense_scale_d, vgrid(ld), ld, (const double *)d->dz, (const double *)d->Dg, d->dz);
-    for (int kb = nb - 1; kb >= 0; kb--)
-        hipLaunchKernelGGL(k_ldl_bwd, dim3(kb > 0 ? kb : 1), dim3(64), 0, d->stream, (const double *)d->Kd, ld, kb, (const double *)d->Linv, d->dz, d->dxw);
-    d->dsol = d->dxw;
-    return 0;
-}
-__global__ void k_add_to(int n, const double *__restrict__ a, double *__restrict__ y) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[i] = y[i] + a[i];
-}
-static const double WB_RES_TOL = 1e-13;    // relative inf-norm residual accepted for a low-rank solve
-static const int WB_MAX_REFINE = 5;
-static int dense_solve(QpdoDev *d) {
-    const int n = d->n, ld = d->dense_ld, k = d->wb_k;
-    int rc = dense_solve_core(d, d->rhs); if (rc) return rc;
-    if (k == 0) {
-        HIPCHK(hipMemcpyAsync(d->dx, d->dsol, (size_t)n * 8, hipMemcpyDeviceToDevice, d->stream));
-        return 0;
-    }
-    // Low-rank path.  One application  e = z0 - Z (I + W G)^-1 W U z0,  z0 = K0^-1 r,  is the solve with the updated
-    // matrix in exact arithmetic, but the correction cancels the part of z0 along the new rows: with weights 1/mu
-    // up to 1e9 that costs log10(w a'K0^-1 a) digits (measured: 1e-4 relative residual on a 200 x 400 instance).
-    // So it is used as the inner solver of an iterative refinement on the true K = Q + sigma I + A' diag(d) A
-    // (three SpMV per sweep) until the residual is at the level of a fresh factorization; a sweep that stalls, a
-    // NaN or a tiny pivot of I + W G (a downdate removing most of a direction of K0) falls back to refactoring.
-    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
-    LAUNCH(k_absmax_mul, vgrid(n), n, (const double *)d->rhs, (const double *)nullptr, d->ctrl, N_A);
-    bool ok = false;
-    double prev = 0.0;
-    for (int it = 0; it <= WB_MAX_REFINE; it++) {
-        if (it > 0) { rc = dense_solve_core(d, d->pc_r); if (rc) return rc; }
-        hipLaunchKernelGGL(k_wb_v, dim3(k), dim3(64), 0, d->stream, (const int *)d->wb_rows, d->Ar.rp, d->Ar.ci, d->Ar.val, (const double *)d->dsol,
-                           (const double *)d->d, (const double *)d->d_fact, d->wb_v, d->wb_w);
-        hipLaunchKernelGGL(k_wb_lu, dim3(1), dim3(1024), (size_t)k * (k + 2) * 8, d->stream, k, (const double *)d->wb_G, (const double *)d->wb_w,
-                           (const double *)d->wb_v, d->wb_t);
-        if (it == 0) {
-            LAUNCH(k_wb_apply, vgrid(n), n, ld, k, (const double *)d->wb_Z, (const double *)d->wb_t, (const double *)d->dsol, d->dx);
-        } else {
-            LAUNCH(k_wb_apply, vgrid(n), n, ld, k, (const double *)d->wb_Z, (const double *)d->wb_t, (const double *)d->dsol, d->pc_z);
-            LAUNCH(k_add_to, vgrid(n), n, (const double *)d->pc_z, d->dx);
-        }
-        // r = rhs - K dx
-        LAUNCH(k_ctrl_set_nrm0, 1, d->ctrl, N_B);
-        launch_spmv(d, d->Ar, d->dx, EpiPcgA{d->d, d->tmp_m, nullptr}, false);
-        launch_spmv(d, d->Qf, d->dx, EpiPcgQ{d->dx, d->sigma_f, d->pc_Kp}, false);
-        launch_spmv(d, d->At, d->tmp_m, EpiResid{d->rhs, d->pc_Kp, d->pc_r, d->ctrl, N_B}, true);
-        double minpiv = 0.0;
-        HIPCHK(hipMemcpyAsync(&minpiv, d->wb_t + WB_MAX, sizeof(double), hipMemcpyDeviceToHost, d->stream));
-        rc = read_ctrl(d); if (rc) return rc;
-        const double nb_ = nrm_of(d->hctrl, N_A), nr_ = nrm_of(d->hctrl, N_B);
-        d->st.lowrank_sweeps++;
-        if (!(minpiv >= WB_MIN_PIVOT)) break;
-        if (nr_ <= WB_RES_TOL * nb_) { ok = true; break; }
-        if (it > 0 && !(nr_ < 0.25 * prev)) { ok = nr_ <= 1e3 * WB_RES_TOL * nb_; break; }      // stalled: accept only near the floor
-        prev = nr_;
-    }
-    if (ok) { d->st.lowrank_solves++; return 0; }
-    d->st.lowrank_rejects++;
-    rc = dense_factor(d); if (rc) return rc;
-    rc = dense_solve_core(d, d->rhs); if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(d->dx, d->dsol, (size_t)n * 8, hipMemcpyDeviceToDevice, d->stream));
-    return 0;
-}
-// Give every row whose weight differs from the factored one a low-rank slot; new slots get their column of
-// Z = K0^-1 U' (multi right-hand-side MFMA block solve) and their row and column of G.  *overflow = 1: more
-// than WB_MAX rows differ, the caller refactors.
-static int wb_extend(QpdoDev *d, int *overflow) {
-    const int ld = d->dense_ld, nb = d->dense_nblk, k_old = d->wb_k;
-    *overflow = 0;
-    hipLaunchKernelGGL(k_wb_select, dim3(1), dim3(1024), 0, d->stream, d->m, (const double *)d->d, (const double *)d->d_fact, d->wb_slot, d->wb_rows,
-                       k_old, d->wb_cnt);
-    int cnt = 0;
-    HIPCHK(hipMemcpyAsync(&cnt, d->wb_cnt, sizeof(int), hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    if (cnt > WB_MAX) { *overflow = 1; return 0; }
-    const int k_new = cnt - k_old;
-    if (k_new <= 0) return 0;
-    const int nr = (k_new + 15) / 16 * 16;                 // padding columns are zero right-hand sides (buffers hold WB_MAX + 16)
-    double *X = d->wb_Z + (size_t)k_old * ld, *T = d->wb_T + (size_t)k_old * ld;
-    hipLaunchKernelGGL(k_wb_rhs, dim3(nr), dim3(256), 0, d->stream, ld, k_old, k_new, (const int *)d->wb_rows, d->Ar.rp, d->Ar.ci, d->Ar.val, d->wb_Z);
-    const size_t lds_f = (size_t)(DNB * 80 + nr * 68) * 8, lds_b = (size_t)(DNB * 68 + nr * 68) * 8;
-    for (int kb = 0; kb < nb; kb++) {
-        const int below = nb - kb - 1;
-        hipLaunchKernelGGL(k_ldl_fwd_mr, dim3(below > 0 ? below : 1), dim3(256), lds_f, d->stream, (const double *)d->Kd, ld, kb, (const double *)d->Linv, X, T, nr, nb);
-    }
-    LAUNCH(k_scale_d_mr, vgrid(ld) * 4, ld, nr, (const double *)d->Dg, T);
-    for (int kb = nb - 1; kb >= 0; kb--)
-        hipLaunchKernelGGL(k_ldl_bwd_mr, dim3(kb > 0 ? kb : 1), dim3(256), lds_b, d->stream, (const double *)d->Kd, ld, kb, (const double *)d->Linv, T, X, nr);
-    hipLaunchKernelGGL(k_wb_G, dim3(cnt, k_new), dim3(64), 0, d->stream, k_old, (const int *)d->wb_rows, d->Ar.rp, d->Ar.ci, d->Ar.val,
-                       (const double *)d->wb_Z, ld, d->wb_G);
-    HIPCHK(hipGetLastError());
-    d->wb_k = cnt;
-    d->st.lowrank_cols += k_new;
-    return 0;
-}
-
-// ---- linesearch sort + scan + search (shared by the Newton step and the parity entry point) -----------
-static int linesearch_device(QpdoDev *d, int pm, int pn) {
-    const int M2 = 2 * d->m;
-    int cur = 0;
-    for (int pass = 0; pass < 8; pass++) {
-        const int shift = 8 * pass;
-        LAUNCH(k_rs_hist, d->rs_nblocks, d->ls_key[cur], M2, shift, d->rs_nblocks, d->rs_hist);
-        LAUNCH(k_rs_scan, 1, d->rs_hist, 256 * d->rs_nblocks);
-        LAUNCH(k_rs_scatter, d->rs_nblocks, d->ls_key[cur], d->ls_idx[cur], d->ls_key[1 - cur], d->ls_idx[1 - cur], M2, shift,
-               d->rs_nblocks, d->rs_hist);
-        cur = 1 - cur;
-    }
-    // 8 passes: result back in buffer 0
-    LAUNCH(k_ls_scan1, d->ls_nblk, d->ctrl, d->ls_idx[cur], d->ls_delta, d->ls_alpha, d->ls_pa, d->ls_pb, d->ls_bt, d->ls_nblk);
-    LAUNCH(k_ls_scan2, 1, d->ctrl, d->part, pm, pn, d->ls_bt, d->ls_nblk);
-    LAUNCH(k_ls_search, vgrid(M2), d->ctrl, d->ls_key[cur], d->ls_pa, d->ls_pb, d->ls_bt, d->ls_nblk);
-    LAUNCH(k_ls_final, 1, d->ctrl, d->ls_pa, d->ls_pb, d->ls_bt, d->ls_nblk);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-// ---- one Newton step (iteration.c:11-25) ----------------------------------------------------------------
-int qdev_newton_step(QpdoDev *d, int branch, int n_changed, int proximal, double sigma, double *tau_out, int *lin_iters_out) {
-    HIPCHK(hipSetDevice(d->device));
-    const int n = d->n, m = d->m;
-    if (branch == 0 || branch == 2) d->sigma_f = proximal ? sigma : 0.0;     // ldlchol beta (cholmod_interface.c:11-13)
-    LAUNCH(k_newton_prep, vgrid(m), m, branch, d->active, d->active_old, d->isq, d->mu, d->res_prim_in, d->d, d->dy);
-    int lin = 0, rc = 0;
-    rc = spmv_At(d, d->dy, EpiRhs{d->res_dual_in, d->Atdy, d->rhs}, false); if (rc) return rc;
-    // the dense factor stays valid only while (sigma_f, d) is unchanged: full refactor (0) always rebuilds,
-    // rank update (1) changes d iff rows entered or left, Q-only (2) is unchanged if the previous factor
-    // was also Q-only at the same sigma
-    if (branch == 0) d->dense_valid = 0;
-    else if (branch == 1) { if (n_changed > 0) d->dense_valid = 0; }
-    else if (!(d->dense_last_branch == 2 && d->dense_last_sigma == d->sigma_f)) d->dense_valid = 0;
-    if (d->linsolve == 1) {
-        if (!d->dense_valid) {
-            // reference: full factorization in branch 0, rank update of the kept factor otherwise (newton.c:21-33)
-            bool full = !d->dense_factored || branch == 0 || !d->wb_enable || d->sigma_f != d->dense_fact_sigma;
-            if (!full) {
-                int overflow = 0;
-                rc = wb_extend(d, &overflow); if (rc) return rc;
-                if (overflow) full = true; else d->dense_valid = 1;
-            }
-            if (full) { rc = dense_factor(d); if (rc) return rc; }
-        }
-        rc = dense_solve(d); if (rc) return rc;
-    } else {
-        rc = pcg_solve(d, &lin); if (rc) return rc;
-    }
-    d->dense_last_branch = branch; d->dense_last_sigma = d->sigma_f;
-    d->st.lin_iters += lin;
-    *lin_iters_out = lin;
-    // Qdx (+ sigma dx), n-side dots
-    launch_spmv(d, d->Qf, d->dx, EpiQdx{d->dx, d->df, sigma, proximal, d->Qdx, d->part + P_DXQDX * PGRID, d->part + P_DXDF * PGRID}, true);
-    LAUNCH(k_ctrl_set_int, 1, d->ctrl, C_NL, 0);
-    EpiAdxLs e{};
-    e.m = m; e.mu = d->mu; e.isq = d->isq; e.w = d->w; e.l = d->l; e.u = d->u; e.y = d->y; e.active = d->active; e.active_old = d->active_old;
-    e.Adx = d->Adx; e.dy = d->dy; e.delta = d->ls_delta; e.alpha = d->ls_alpha; e.key = d->ls_key[0]; e.idx = d->ls_idx[0];
-    e.p_eta = d->part + P_ETA_M * PGRID; e.p_beta = d->part + P_BETA_M * PGRID; e.p_a0 = d->part + P_A0 * PGRID; e.p_b0 = d->part + P_B0 * PGRID;
-    e.ctrl = d->ctrl;
-    rc = spmv_A(d, d->dx, e, true); if (rc) return rc;
-    rc = spmv_At(d, d->dy, EpiStore{d->Atdy}, false); if (rc) return rc;
-    rc = linesearch_device(d, pgrid_A(d), spmv_pgrid(d->Qf)); if (rc) return rc;
-    LAUNCH(k_axpy5, vgrid(n > m ? n : m), n, m, d->ctrl, d->x, d->dx, d->Qx, d->Qdx, d->Aty, d->Atdy, d->y, d->dy, d->Ax, d->Adx);
-    rc = read_ctrl(d); if (rc) return rc;
-    if (d->linsolve == 1 && d->dense_chain && d->hctrl->cnt[C_CHAIN_ERR]) return set_err(hipErrorUnknown, "dense triangular solve: lost producer", __LINE__);
-    *tau_out = d->hctrl->val[V_TAU];
-    d->st.newton_passes++;
-    return 0;
-}
-
-// ---- outer-update helpers ---------------------------------------------------------------------------------
-int qdev_primal_infeasibility(QpdoDev *d, double eps_prim_inf, int *is_infeasible) {
-    HIPCHK(hipSetDevice(d->device));
-    const int n = d->n, m = d->m;
-    *is_infeasible = 0;
-    LAUNCH(k_sub, vgrid(m), m, d->y, d->ybar, d->dy);                                  // qpdo.c:372
-    { int rc2 = spmv_At(d, d->dy, EpiStore{d->Atdy}, false); if (rc2) return rc2; }       // qpdo.c:374
-    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
-    LAUNCH(k_absmax_mul, vgrid(m), m, (const double *)d->dy, d->scaled ? (const double *)d->E : (const double *)nullptr, d->ctrl, N_A);
-    int rc = read_ctrl(d); if (rc) return rc;
-    const double eps = eps_prim_inf * nrm_of(d->hctrl, N_A);
-    if (eps == 0) return 0;
-    LAUNCH(k_pinf_n, vgrid(n), n, d->scaled, d->Dinv, d->Atdy, d->ctrl);
-    const int g = vgrid(m);
-    LAUNCH(k_pinf_m, g, m, d->scaled, d->dy, d->l, d->u, d->E, d->part + P_OOB * PGRID);
-    LAUNCH(k_reduce_to_ctrl, 1, d->part + P_OOB * PGRID, g, d->ctrl, V_OOB);
-    rc = read_ctrl(d); if (rc) return rc;
-    const double nAtdy = nrm_of(d->hctrl, N_B), oob = d->hctrl->val[V_OOB];
-    if ((nAtdy <= eps) && (oob <= -eps)) {
-        *is_infeasible = 1;
-        if (d->scaled) LAUNCH(k_pinf_cert, vgrid(m), m, d->sc_cinv, d->E, d->dy);
-    }
-    return 0;
-}
-int qdev_dual_infeasibility(QpdoDev *d, int proximal, double sigma, double tau, double eps_dual_inf, int *is_infeasible) {
-    HIPCHK(hipSetDevice(d->device));
-    const int n = d->n, m = d->m;
-    *is_infeasible = 0;
-    LAUNCH(k_sub, vgrid(n), n, d->x, d->xbar, d->dx);                                  // qpdo.c:383
-    launch_spmv(d, d->Qf, d->dx, EpiStore{d->Qdx}, false);                             // qpdo.c:385 (no sigma)
-    { int rc2 = spmv_A(d, d->dx, EpiStore{d->Adx}, false); if (rc2) return rc2; }        // qpdo.c:387
-    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
-    LAUNCH(k_absmax_mul, vgrid(n), n, (const double *)d->dx, d->scaled ? (const double *)d->D : (const double *)nullptr, d->ctrl, N_C);
-    int rc = read_ctrl(d); if (rc) return rc;
-    const double eps = eps_dual_inf * nrm_of(d->hctrl, N_C);
-    if (eps == 0) return 0;
-    LAUNCH(k_dinf_m, vgrid(m), m, d->scaled, eps, d->Einv, d->E, d->l, d->u, d->Adx, d->ctrl);
-    rc = read_ctrl(d); if (rc) return rc;
-    if (d->hctrl->cnt[C_VIOL]) return 0;
-    const int g = vgrid(n);
-    LAUNCH(k_dinf_n, g, n, proximal, -sigma * tau, d->dx, d->q, d->Qdx, d->ctrl, d->part + P_QDX * PGRID);
-    LAUNCH(k_reduce_to_ctrl, 1, d->part + P_QDX * PGRID, g, d->ctrl, V_QDX);
-    rc = read_ctrl(d); if (rc) return rc;
-    const double nQdx = nrm_of(d->hctrl, N_D), qdx = d->hctrl->val[V_QDX];
-    const double c = d->scaled ? d->sc_c : 1.0;
-    const bool ok = d->scaled ? ((nQdx <= c * eps) && (qdx <= -c * eps)) : ((nQdx <= eps) && (qdx <= -eps));
-    if (ok) {
-        *is_infeasible = 1;
-        if (d->scaled) LAUNCH(k_mul, vgrid(n), n, d->D, d->dx, d->dx);
-    }
-    return 0;
-}
-int qdev_shift_estimates(QpdoDev *d) {
-    HIPCHK(hipSetDevice(d->device));
-    HIPCHK(hipMemcpyAsync(d->xbar, d->x, (size_t)d->n * 8, hipMemcpyDeviceToDevice, d->stream));
-    if (d->m) HIPCHK(hipMemcpyAsync(d->ybar, d->y, (size_t)d->m * 8, hipMemcpyDeviceToDevice, d->stream));
-    return 0;
-}
-int qdev_update_mu(QpdoDev *d, double eps_abs, double theta, double delta, double mu_min, double isq_mu_min, int *n_changed) {
-    HIPCHK(hipSetDevice(d->device));
-    const int m = d->m;
-    LAUNCH(k_ctrl_clear_aux, 1, d->ctrl);
-    LAUNCH(k_absmax_mul, vgrid(m), m, (const double *)d->res_prim, (const double *)nullptr, d->ctrl, N_A);     // iteration.c:130
-    LAUNCH(k_update_mu, vgrid(m), m, eps_abs, theta, delta, mu_min, isq_mu_min, (const Ctrl *)d->ctrl, d->res_prim, d->res_prim_old,
-           d->mu, d->isq, d->at_scale, d->mu_changed, d->ctrl);
-    int rc = read_ctrl(d); if (rc) return rc;
-    *n_changed = d->hctrl->cnt[C_MUCH];
-    return 0;
-}
-int qdev_mu_changed_update(QpdoDev *d) {
-    HIPCHK(hipSetDevice(d->device));
-    LAUNCH(k_mu_changed_d, vgrid(d->m), d->m, d->mu_changed, d->at_scale, d->isq, d->d);
-    d->dense_valid = 0;
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-int qdev_update_sigma(QpdoDev *d, double sigma_new, double sigma_old) {
-    HIPCHK(hipSetDevice(d->device));
-    LAUNCH(k_axpy, vgrid(d->n), d->n, sigma_new - sigma_old, d->x, d->Qx);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-int qdev_save_res_prim(QpdoDev *d) {
-    HIPCHK(hipSetDevice(d->device));
-    if (d->m) HIPCHK(hipMemcpyAsync(d->res_prim_old, d->res_prim, (size_t)d->m * 8, hipMemcpyDeviceToDevice, d->stream));
-    return 0;
-}
-int qdev_store_solution(QpdoDev *d, double *sol_x, double *sol_y, double *x, double *y, double *dx, double *dy) {
-    HIPCHK(hipSetDevice(d->device));
-    const int n = d->n, m = d->m;
-    LAUNCH(k_store_solution, vgrid(n > m ? n : m), n, m, d->scaled, d->sc_cinv, d->x, d->D, d->y, d->E, d->tmp_n, d->tmp_m);
-    HIPCHK(hipMemcpyAsync(sol_x, d->tmp_n, (size_t)n * 8, hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipMemcpyAsync(x, d->x, (size_t)n * 8, hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipMemcpyAsync(dx, d->dx, (size_t)n * 8, hipMemcpyDeviceToHost, d->stream));
-    if (m) {
-        HIPCHK(hipMemcpyAsync(sol_y, d->tmp_m, (size_t)m * 8, hipMemcpyDeviceToHost, d->stream));
-        HIPCHK(hipMemcpyAsync(y, d->y, (size_t)m * 8, hipMemcpyDeviceToHost, d->stream));
-        HIPCHK(hipMemcpyAsync(dy, d->dy, (size_t)m * 8, hipMemcpyDeviceToHost, d->stream));
-    }
-    HIPCHK(hipStreamSynchronize(d->stream));
-    return 0;
-}
-
-// ---- measurement + parity entry points ---------------------------------------------------------------------
-static DevCsr *mat_by_id(QpdoDev *d, int which) { return which == 0 ? &d->Ar : which == 1 ? &d->At : &d->Qf; }
-
-int qdev_bench_spmv(QpdoDev *d, int which, int reps, double *avg_seconds, double *alg_bytes) {
-    HIPCHK(hipSetDevice(d->device));
-    DevCsr *M = mat_by_id(d, which);
-    double *xin = (M->ncols == d->n) ? d->pc_p : d->pc_t;
-    double *yout = (M->nrows == d->n) ? d->pc_Kp : d->tmp_m;
-    LAUNCH(k_fill, vgrid(M->ncols), M->ncols, 1.0, xin);
-    launch_spmv(d, *M, xin, EpiStore{yout}, false);     // warm-up
-    HIPCHK(hipEventRecord(d->ev0, d->stream));
-    for (int r = 0; r < reps; r++) launch_spmv(d, *M, xin, EpiStore{yout}, false);
-    HIPCHK(hipEventRecord(d->ev1, d->stream));
-    HIPCHK(hipEventSynchronize(d->ev1));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, d->ev0, d->ev1));
-    *avg_seconds = (double)ms * 1e-3 / (double)reps;
-    *alg_bytes = M->alg_bytes();
-    return 0;
-}
-int qdev_spmv(QpdoDev *d, int which, const double *v_host, double *y_host) {
-    HIPCHK(hipSetDevice(d->device));
-    DevCsr *M = mat_by_id(d, which);
-    double *xin = (M->ncols == d->n) ? d->pc_p : d->pc_t;
-    double *yout = (M->nrows == d->n) ? d->pc_Kp : d->tmp_m;
-    if (M->ncols) HIPCHK(hipMemcpyAsync(xin, v_host, (size_t)M->ncols * 8, hipMemcpyHostToDevice, d->stream));
-    launch_spmv(d, *M, xin, EpiStore{yout}, false);
-    if (M->nrows) HIPCHK(hipMemcpyAsync(y_host, yout, (size_t)M->nrows * 8, hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    return 0;
-}
-int qdev_linesearch(QpdoDev *d, double eta, double beta, const double *delta, const double *alpha, double *tau) {
-    HIPCHK(hipSetDevice(d->device));
-    const int M2 = 2 * d->m;
-    if (M2 == 0) { *tau = -beta / eta; return 0; }
-    HIPCHK(hipMemcpyAsync(d->ls_delta, delta, (size_t)M2 * 8, hipMemcpyHostToDevice, d->stream));
-    HIPCHK(hipMemcpyAsync(d->ls_alpha, alpha, (size_t)M2 * 8, hipMemcpyHostToDevice, d->stream));
-    LAUNCH(k_ctrl_set_int, 1, d->ctrl, C_NL, 0);
-    const int g = vgrid(M2);
-    LAUNCH(k_ls_prep_raw, g, M2, d->ls_delta, d->ls_alpha, d->ls_key[0], d->ls_idx[0], d->part + P_A0 * PGRID, d->part + P_B0 * PGRID, d->ctrl);
-    // eta, beta enter through the partial slots so that k_ls_scan2 forms a0, b0 exactly as in a Newton step:
-    // eta = 0.5*(eta_m + dxQdx) with eta_m = 2*eta, dxQdx = 0
-    hipLaunchKernelGGL(k_set_partial, dim3(1), dim3(1), 0, d->stream, d->part + P_ETA_M * PGRID, 2.0 * eta);
-    hipLaunchKernelGGL(k_set_partial, dim3(1), dim3(1), 0, d->stream, d->part + P_BETA_M * PGRID, 2.0 * beta);
-    hipLaunchKernelGGL(k_set_partial, dim3(1), dim3(1), 0, d->stream, d->part + P_DXQDX * PGRID, 0.0);
-    hipLaunchKernelGGL(k_set_partial, dim3(1), dim3(1), 0, d->stream, d->part + P_DXDF * PGRID, 0.0);
-    // pm applies to ETA/BETA (1 value) and A0/B0 (g values): run scan2 with pm = g after zero-padding ETA/BETA slots
-    if (g > 1) {
-        HIPCHK(hipMemsetAsync(d->part + P_ETA_M * PGRID + 1, 0, (size_t)(g - 1) * 8, d->stream));
-        HIPCHK(hipMemsetAsync(d->part + P_BETA_M * PGRID + 1, 0, (size_t)(g - 1) * 8, d->stream));
-    }
-    int rc = linesearch_device(d, g, 1); if (rc) return rc;
-    rc = read_ctrl(d); if (rc) return rc;
-    *tau = d->hctrl->val[V_TAU];
-    return 0;
-}
-
+#include "dev/host_setup.inc"
+#include "dev/host_pcg.inc"
+#include "dev/host_dense.inc"
+#include "dev/host_step.inc"
 }  // extern "C"
