@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256) void k_slab_permute(int nrows, int nslabs, int
         }
 }
 // production-form kernel: int2 segment table, ternary masking of the products; UNR 16-byte loads in flight per lane
-template <int TPR, int UNR>
-__global__ __launch_bounds__(1024) void k_slab_prod(int nrows, int ncols, int nslabs, int W, int rows_per_wg, const int2 *__restrict__ seg,
+template <int TPR, int UNR, int NT = 1024>
+__global__ __launch_bounds__(NT) void k_slab_prod(int nrows, int ncols, int nslabs, int W, int rows_per_wg, const int2 *__restrict__ seg,
                                                     const unsigned short *__restrict__ i16sm, const double *__restrict__ vsm,
                                                     const double *__restrict__ x, double *__restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -201,13 +201,13 @@ __global__ __launch_bounds__(1024) void k_slab_prod(int nrows, int ncols, int ns
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * rows_per_wg;
     const int R = min(rows_per_wg, nrows - row0);
-    for (int r = tid; r < R; r += 1024) acc[r] = 0.0;
+    for (int r = tid; r < R; r += NT) acc[r] = 0.0;
     const int lane = tid & (TPR - 1);
     for (int s = 0; s < nslabs; s++) {
         const int c0 = s * W, cw = min(W, ncols - c0);
         __syncthreads();
         { const int pairs = cw >> 1; const double2 *src = reinterpret_cast<const double2 *>(x + c0); double2 *dst = reinterpret_cast<double2 *>(xs);
-          for (int i = tid; i < pairs; i += 1024) dst[i] = src[i];
+          for (int i = tid; i < pairs; i += NT) dst[i] = src[i];
           if ((cw & 1) && tid == 0) xs[cw - 1] = x[c0 + cw - 1];
           if (tid == 0) next_row = 0; }
         __syncthreads();
@@ -251,7 +251,44 @@ __global__ __launch_bounds__(1024) void k_slab_prod(int nrows, int ncols, int ns
         }
     }
     __syncthreads();
-    for (int r = tid; r < R; r += 1024) y[row0 + r] = acc[r];
+    for (int r = tid; r < R; r += NT) y[row0 + r] = acc[r];
+}
+
+__global__ void k_rebuild(int m, int per_row, int nslabs, int W, const int *__restrict__ ci, unsigned short *__restrict__ ci16, int *__restrict__ sp) {
+    for (int r = blockIdx.x; r < m; r += gridDim.x) {
+        const size_t b = (size_t)r * per_row;
+        for (int j = threadIdx.x; j < per_row; j += blockDim.x) ci16[b + j] = (unsigned short)(ci[b + j] % W);
+        if (threadIdx.x <= nslabs) {
+            const int s = threadIdx.x; int lo = 0, hi = per_row;
+            if (s == nslabs) lo = per_row; else { const int target = s * W; while (lo < hi) { int mid = (lo + hi) >> 1; if (ci[b + mid] < target) lo = mid + 1; else hi = mid; } }
+            sp[(size_t)r * (nslabs + 1) + s] = (int)(b + lo);
+        }
+    }
+}
+
+template <int TPR, int UNR, int NT>
+static void run_prod_wg(const char *name, int m, int n, int nwg, const int *sp0, int nslabs0, const unsigned short *ci16_rm, const int *ci_rm, const double *val_rm, const double *x, double *y, double nnz) {
+    // rebuild slab tables for this (W, rows-per-wg): W from the LDS budget of one workgroup
+    const int rpw = (m + nwg - 1) / nwg;
+    const int lds_budget = (NT == 1024 ? (160 * 1024 - 1024) : (80 * 1024 - 1024)) / 8 - rpw;
+    int nslabs = (n + lds_budget - 1) / lds_budget; int W = (((n + nslabs - 1) / nslabs) + 63) & ~63; if (W > lds_budget) { nslabs++; W = (((n + nslabs - 1) / nslabs) + 63) & ~63; }
+    int *sp; int2 *seg; unsigned short *i16, *i16sm; double *vsm;
+    CK(hipMalloc(&sp, (size_t)m * (nslabs + 1) * 4)); CK(hipMalloc(&seg, (size_t)m * nslabs * 8)); CK(hipMalloc(&i16, (size_t)nnz * 2)); CK(hipMalloc(&i16sm, ((size_t)nnz + 4) * 2)); CK(hipMalloc(&vsm, ((size_t)nnz + 4) * 8));
+    CK(hipMemset(i16sm, 0, ((size_t)nnz + 4) * 2)); CK(hipMemset(vsm, 0, ((size_t)nnz + 4) * 8));
+    hipLaunchKernelGGL(k_rebuild, dim3(4096), dim3(256), 0, 0, m, (int)(nnz / m), nslabs, W, ci_rm, i16, sp);
+    hipLaunchKernelGGL(k_slab_seg, dim3((m + rpw - 1) / rpw), dim3(1024), 0, 0, m, nslabs, rpw, (const int *)sp, seg);
+    hipLaunchKernelGGL(k_slab_permute, dim3(2048), dim3(256), 0, 0, m, nslabs, W, (const int *)sp, (const int2 *)seg, (const unsigned short *)i16, val_rm, vsm, i16sm);
+    CK(hipDeviceSynchronize());
+    const int grid = (m + rpw - 1) / rpw; const size_t lds = (size_t)(W + rpw) * 8;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slab_prod<TPR, UNR, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL((k_slab_prod<TPR, UNR, NT>), dim3(grid), dim3(NT), lds, 0, m, n, nslabs, W, rpw, (const int2 *)seg, (const unsigned short *)i16sm, (const double *)vsm, x, y);
+    CK(hipEventRecord(e0, 0));
+    for (int w = 0; w < 10; w++) hipLaunchKernelGGL((k_slab_prod<TPR, UNR, NT>), dim3(grid), dim3(NT), lds, 0, m, n, nslabs, W, rpw, (const int2 *)seg, (const unsigned short *)i16sm, (const double *)vsm, x, y);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+    printf("%-44s wg %4d x %4d thr, W %5d, %2d slabs: %.3f ms  algorithmic %.2f TB/s\n", name, grid, NT, W, nslabs, ms, nnz * 12 / ms / 1e9); fflush(stdout);
+    CK(hipFree(sp)); CK(hipFree(seg)); CK(hipFree(i16)); CK(hipFree(i16sm)); CK(hipFree(vsm));
 }
 template <int TPR, int UNR>
 static void run_prod(const char *name, int m, int n, int nslabs, int W, int rpw, const int2 *seg, const unsigned short *i16, const double *v, const double *x, double *y, double nnz, const std::vector<double> &ref) {
@@ -338,6 +375,16 @@ int main() {
         run_prod<8, 12>("PROD row-major tpr8 unr12", m, n, nslabs, W, rpw, segrm, ci16, val, x, y, nnz, ref);
         CK(hipFree(segrm));
         CK(hipFree(vsm)); CK(hipFree(i16sm)); CK(hipFree(seg));
+    }
+    {   // compact-shaped product (k = 73000 active rows): workgroup geometry
+        const int kk = 73000; const double nnzk = (double)kk * per_row;
+        printf("compact shape k=%d\n", kk);
+        run_prod_wg<16, 8, 1024>("1024 thr, 1 wg/CU (production)", kk, n, 256, sp, nslabs, ci16, ci, val, x, y, nnzk);
+        run_prod_wg<16, 8, 512>("512 thr, 2 wg/CU", kk, n, 512, sp, nslabs, ci16, ci, val, x, y, nnzk);
+        run_prod_wg<16, 8, 512>("512 thr, 2 wg/CU, 1024 wgs", kk, n, 1024, sp, nslabs, ci16, ci, val, x, y, nnzk);
+        run_prod_wg<16, 8, 1024>("1024 thr, 512 wgs (2 waves of wgs)", kk, n, 512, sp, nslabs, ci16, ci, val, x, y, nnzk);
+        run_prod_wg<16, 8, 1024>("full m, production geometry", m, n, 256, sp, nslabs, ci16, ci, val, x, y, nnz);
+        run_prod_wg<16, 8, 512>("full m, 512 thr 2 wg/CU", m, n, 512, sp, nslabs, ci16, ci, val, x, y, nnz);
     }
     // ---- slab-major storage: per workgroup, all row segments of slab 0, then of slab 1, ... (sequential stream per slab phase)
     {
