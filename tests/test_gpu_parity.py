@@ -95,8 +95,14 @@ def test_scaling_is_bit_exact(gpu_required):
     s.delete(); o.close()
 
 
-@pytest.mark.parametrize("shape", [(200, 100, 0.1), (50, 1000, 0.3), (3000, 4000, 0.01)])
-def test_spmv_matches_oracle(shape, gpu_required):
+@pytest.mark.parametrize("kernel", ["auto", "slab-i16", "slab-i32"])
+@pytest.mark.parametrize("shape", [(200, 100, 0.1), (50, 1000, 0.3), (3000, 4000, 0.01), (700, 300, 0.37)])
+def test_spmv_matches_oracle(shape, kernel, gpu_required, monkeypatch):
+    """plain gather kernel (auto at these sizes) and the LDS-staged slab kernel over the slab-major image with
+    16-bit slab-local or 32-bit column indices"""
+    if kernel != "auto":
+        monkeypatch.setenv("QPDO_SPMV", "slab")
+        monkeypatch.setenv("QPDO_IDX16", "1" if kernel == "slab-i16" else "0")
     n, m, dens = shape
     p = problems.random_qp(31, n, m, dens)
     s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0, scaling=0)
