@@ -19,7 +19,8 @@ out = []
 for name, p, st in [("C1", problems.config_qp("C1"), dict(max_iter=200)),
                     ("rand_eq", problems.random_qp(23, 150, 300, 0.05, 50), {}),
                     ("kat_pinf", problems.infeasibility_kat("primal_infeasible"), dict(max_iter=100)),
-                    ("noscale", problems.random_qp(24, 300, 200, 0.03), dict(scaling=0))]:
+                    ("noscale", problems.random_qp(24, 300, 200, 0.03), dict(scaling=0)),
+                    ("schur", problems.random_qp(61, 700, 1400, 0.03, 0), {})]:   # enough active rows for the Schur-complement mode
     r = solver.solve_problem(p, verbose=0, **st)
     if rank == 0:
         o = ob.OracleSolver(p, ob.default_settings(**st)); ro = o.solve()
@@ -29,7 +30,8 @@ for name, p, st in [("C1", problems.config_qp("C1"), dict(max_iter=200)),
             err = 0.0
         else:
             err = float(max(np.abs(r["x"] - ro["x"]).max(), np.abs(r["y"] - ro["y"]).max()))
-        out.append(dict(name=name, ok_counts=bool(ok_counts), err=err, status=r["info"]["status_val"], linsolve=r["stats"]["linsolve"]))
+        out.append(dict(name=name, ok_counts=bool(ok_counts), err=err, status=r["info"]["status_val"], linsolve=r["stats"]["linsolve"],
+                        schur_passes=r["stats"]["schur_passes"]))
         o.close()
     # every rank must hold the same solution
     chk = np.nan_to_num(np.concatenate([r["x"], r["y"]]))

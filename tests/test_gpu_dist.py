@@ -20,7 +20,11 @@ def test_row_partitioned_solve_matches_oracle(world, gpu_required):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     line = [l for l in out.stdout.splitlines() if l.startswith("[{")][-1]
-    for r in json.loads(line):
+    res = json.loads(line)
+    for r in res:
         assert r["ok_counts"], r
         assert r["err"] <= 1e-8, r
         assert r["linsolve"] == 0
+    # the larger instance must have gone through the row-partitioned Schur-complement mode (global compact index space,
+    # two all-reduces per inner iteration)
+    assert [r for r in res if r["name"] == "schur"][0]["schur_passes"] > 0
