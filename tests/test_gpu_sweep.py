@@ -93,3 +93,30 @@ def test_fused_batch_sweep_is_bit_identical(gpu_required):
         if not ok:
             bad.append((i, p["n"], p["m"], oi["status_val"], gi["status_val"], oi["iterations"], gi["iterations"]))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_schur_mode_mid_size_instances_match_oracle(i, gpu_required, monkeypatch):
+    """instances large enough (k >= 256 active rows) for the Schur-complement mode of the PCG, with equality rows,
+    one-sided rows and perturbed settings, against the oracle's direct solves"""
+    monkeypatch.setenv("QPDO_LINSOLVE", "pcg")
+    monkeypatch.setenv("QPDO_PCG_SCHUR", "1")
+    rng = np.random.default_rng(300 + i)
+    n = int(rng.integers(500, 900)); m = int(rng.integers(900, 2000))
+    neq = int(rng.integers(0, 120)) if i % 2 else 0
+    p = problems.random_qp(8000 + i, n, m, float(rng.choice([0.02, 0.05])), neq)
+    kind = rng.random(m)
+    l, u = p["l"].copy(), p["u"].copy()
+    l[(kind < 0.1) & (np.arange(m) >= neq)] = -1e20
+    u[(kind > 0.9) & (np.arange(m) >= neq)] = 1e20
+    p["l"], p["u"] = l, u
+    st = [dict(), dict(scaling=0), dict(eps_abs=1e-8), dict(proximal=0), dict(sigma_init=1e-1), dict(scaling=3, mu_min=1e-6)][i]
+    o = ob.OracleSolver(p, ob.default_settings(**st))
+    ro = o.solve()
+    oi, ox, oy = dict(ro["info"]), np.array(ro["x"]), np.array(ro["y"])
+    o.close()
+    r = solver.solve_problem(p, verbose=0, **st)
+    gi = r["info"]
+    assert (gi["status_val"], gi["iterations"], gi["oterations"]) == (oi["status_val"], oi["iterations"], oi["oterations"])
+    assert r["stats"]["schur_passes"] > 0
+    assert close_vec(r["x"], ox, 1e-7) and close_vec(r["y"], oy, 1e-7)
