@@ -164,11 +164,18 @@ def main():
                     achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
                     alg_bytes_per_launch=ac_bytes / ac_n, avg_launch_s=ac_time / ac_n, samples=int(ac_n),
                     microbench_GBs=full_bytes / bench_t / 1e9, spmv_A_GBs=None, spmv_At_GBs=None)
-        if pmc is not None and a.workload == "C4":
-            ratio = pmc["A  (CSR m x n)"]["traffic_over_alg"]
-            roof["traffic"] = ratio * ac_bytes / ac_n
-            roof["traffic_source"] = ("profiles/r01_pmc_spmv_c4.json: measured HBM bytes / algorithmic bytes = %.3f for the same kernel on the full A "
-                                      "(2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes), applied to the average compact launch" % ratio)
+        if a.workload == "C4":
+            try:      # averaged over all real launches of this kernel in a profiled run of this same command
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_schur_inner_c4.json")) as fh:
+                    pin = json.load(fh)
+                roof["traffic"] = pin["k_spmv_slab<EpiSchurA> (A_c product)"]["traffic_bytes_avg"]
+                roof["traffic_source"] = ("profiles/r01_pmc_schur_inner_c4.json: 2*FETCH_SIZE + WRITE_SIZE averaged over the real launches of this kernel "
+                                          "in separate rocprofv3 --pmc passes over this command")
+            except Exception:
+                if pmc is not None:
+                    ratio = pmc["A  (CSR m x n)"]["traffic_over_alg"]
+                    roof["traffic"] = ratio * ac_bytes / ac_n
+                    roof["traffic_source"] = "profiles/r01_pmc_spmv_c4.json ratio for the same kernel on the full A, applied to the average compact launch"
         if at_n:
             q_t, q_b = s.bench_spmv(2, reps=5)
             roof["spmv_Q_live_GBs"] = q_b / (at_time / at_n) / 1e9
