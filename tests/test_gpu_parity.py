@@ -146,8 +146,14 @@ def test_linesearch_matches_oracle(m, gpu_required):
     s.delete()
 
 
-def test_warm_start_and_update_sequence_matches_oracle(linsolve, gpu_required):
-    p = problems.config_qp("C1")
+@pytest.mark.parametrize("size", ["C1", "mid"])
+def test_warm_start_and_update_sequence_matches_oracle(size, linsolve, gpu_required, monkeypatch):
+    """qpdo_warm_start / qpdo_update_bounds / qpdo_update_q / qpdo_update_settings followed by re-solves on one
+    workspace (reference src/qpdo.c:217-299,481-586).  "mid" is large enough for the Schur-complement mode of the PCG
+    and for the low-rank update of the dense factor to take part in the re-solves."""
+    if size == "mid":
+        monkeypatch.setenv("QPDO_PCG_SCHUR", "1")
+    p = problems.config_qp("C1") if size == "C1" else problems.random_qp(71, 600, 1100, 0.03, 40)
     o = ob.OracleSolver(p, ob.default_settings())
     s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0)
     rt = rtol_of(linsolve)
