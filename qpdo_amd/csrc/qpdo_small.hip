@@ -19,8 +19,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <algorithm>
 #include <vector>
+#include <thread>
+#include <mutex>
+#include <memory>
 
 #include "qpdo.h"
 #include "qpdo_amd_ext.h"
@@ -651,22 +655,48 @@ static void csc_as_csrT32(const cholmod_sparse *M, HostCsr32 &o) {         // CS
 static void sym_full32(const cholmod_sparse *Q, HostCsr32 &o) {            // full symmetric CSR, rows column-sorted
     const int st = Q->stype;
     if (st == 0) { csc_as_csrT32(Q, o); return; }
+    // row i of the full matrix = (lower stored) CSR row i of the stored triangle [columns <= i] followed by the stored column
+    // i below the diagonal, (upper stored) the stored column i above the diagonal followed by CSR row i [columns >= i];
+    // same rule as the host driver's sym_to_full_csr (qpdo_api.c)
     const long long n = (long long)Q->ncol;
-    std::vector<std::vector<std::pair<int, double>>> rows((size_t)n);
+    HostCsr32 R; csc_to_csr32(Q, R);
     const double *x = (const double *)Q->x;
-    for (long long j = 0; j < n; j++)
-        for (long long k = idx_at(Q->p, Q->itype, j); k < idx_at(Q->p, Q->itype, j + 1); k++) {
-            const long long i = idx_at(Q->i, Q->itype, k);
-            if (i == j) rows[(size_t)i].push_back({(int)j, x[k]});
-            else if ((st < 0 && i > j) || (st > 0 && i < j)) { rows[(size_t)i].push_back({(int)j, x[k]}); rows[(size_t)j].push_back({(int)i, x[k]}); }
-        }
     o.rp.assign(n + 1, 0);
-    for (long long r = 0; r < n; r++) {
-        std::stable_sort(rows[(size_t)r].begin(), rows[(size_t)r].end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.first < b.first; });
-        o.rp[r + 1] = o.rp[r] + (int)rows[(size_t)r].size();
+    auto keep_csr = [&](long long i, long long j) { return st < 0 ? j <= i : j >= i; };
+    auto keep_mir = [&](long long i, long long j) { return st < 0 ? i > j : i < j; };
+    for (long long i = 0; i < n; i++) {
+        int c = 0;
+        for (int k = R.rp[i]; k < R.rp[i + 1]; k++) c += keep_csr(i, R.ci[k]);
+        for (long long k = idx_at(Q->p, Q->itype, i); k < idx_at(Q->p, Q->itype, i + 1); k++) c += keep_mir(idx_at(Q->i, Q->itype, k), i);
+        o.rp[i + 1] = o.rp[i] + c;
     }
     o.ci.resize(o.rp[n]); o.val.resize(o.rp[n]);
-    for (long long r = 0; r < n; r++) { int s = o.rp[r]; for (auto &e : rows[(size_t)r]) { o.ci[s] = e.first; o.val[s] = e.second; s++; } }
+    for (long long i = 0; i < n; i++) {
+        int s2 = o.rp[i];
+        const long long b0 = idx_at(Q->p, Q->itype, i), e0 = idx_at(Q->p, Q->itype, i + 1);
+        if (st < 0) {
+            for (int k = R.rp[i]; k < R.rp[i + 1]; k++) if (keep_csr(i, R.ci[k])) { o.ci[s2] = R.ci[k]; o.val[s2] = R.val[k]; s2++; }
+            for (long long k = b0; k < e0; k++) { const long long r = idx_at(Q->i, Q->itype, k); if (keep_mir(r, i)) { o.ci[s2] = (int)r; o.val[s2] = x[k]; s2++; } }
+        } else {
+            for (long long k = b0; k < e0; k++) { const long long r = idx_at(Q->i, Q->itype, k); if (keep_mir(r, i)) { o.ci[s2] = (int)r; o.val[s2] = x[k]; s2++; } }
+            for (int k = R.rp[i]; k < R.rp[i + 1]; k++) if (keep_csr(i, R.ci[k])) { o.ci[s2] = R.ci[k]; o.val[s2] = R.val[k]; s2++; }
+        }
+    }
+}
+// device arena kept between calls (hipMalloc/hipFree of ~0.5 GB cost ~0.1 s per batch); grow-only, one batch at a time
+static std::mutex s_arena_mu;
+static char *s_arena = nullptr; static size_t s_arena_cap = 0; static int s_arena_dev = -1;
+// run f(i) for i in [0, count) on up to 16 host threads
+template <class F>
+static void parallel_items(long count, F f) {
+    unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;
+    long T = hw > 16 ? 16 : (long)hw;
+    if (const char *e = getenv("QPDO_SETUP_THREADS")) { const long v = atol(e); if (v > 0) T = v; }
+    if (T > count / 32 + 1) T = count / 32 + 1;
+    if (T <= 1) { for (long i = 0; i < count; i++) f(i); return; }
+    std::vector<std::thread> th;
+    for (long t = 0; t < T; t++) th.emplace_back([=]() { for (long i = t; i < count; i += T) f(i); });
+    for (auto &x : th) x.join();
 }
 
 extern "C" {
@@ -691,48 +721,67 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
     QPDOAmdBatchItem *items = (QPDOAmdBatchItem *)items_;
     const QPDOSettings *settings = (const QPDOSettings *)settings_;
     int rc = 0;
+    std::lock_guard<std::mutex> arena_lock(s_arena_mu);
     char *dbase = nullptr; hipStream_t stream = nullptr; SmallQP *dprobs = nullptr; long long *dprof = nullptr;
-    std::vector<char> harena; std::vector<SmallQP> hp((size_t)count);
-    std::vector<size_t> off_solx((size_t)count), off_soly((size_t)count), off_dx((size_t)count), off_dy((size_t)count);
+    std::unique_ptr<char[]> harena, hout; std::vector<SmallQP> hp((size_t)count);
+    const bool tprof = getenv("QPDO_SMALL_PROF") && !strcmp(getenv("QPDO_SMALL_PROF"), "2");
+    auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    double tp0 = now();
+    auto lap = [&](const char *what) { if (tprof) { const double t = now(); fprintf(stderr, "[qpdo_small host] %-22s %.3f s\n", what, t - tp0); tp0 = t; } };
     size_t total = 0;
     auto reserve = [&](size_t bytes) { size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; };
     struct Lay { size_t Arp, Aci, Aval, Trp, Tci, Tval, Qrp, Qci, Qval, q, l, u, x0, y0, nv, mv, lsv, iv, K, solx, soly, dx, dy; HostCsr32 A, T, Q; };
     std::vector<Lay> lay((size_t)count);
+    // device arena: [inputs of all items][outputs of all items][scratch]; only the inputs are uploaded and only the
+    // outputs come back.  The per-item conversions and the copies into the staging buffer run on host threads.
+    parallel_items(count, [&](long i) { const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i]; csc_to_csr32(d->A, L.A); csc_as_csrT32(d->A, L.T); sym_full32(d->Q, L.Q); });
     for (long i = 0; i < count; i++) {
         const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
         const size_t n = d->n, m = d->m;
-        csc_to_csr32(d->A, L.A); csc_as_csrT32(d->A, L.T); sym_full32(d->Q, L.Q);
         L.Arp = reserve((m + 1) * 4); L.Aci = reserve(L.A.ci.size() * 4 + 4); L.Aval = reserve(L.A.val.size() * 8 + 8);
         L.Trp = reserve((n + 1) * 4); L.Tci = reserve(L.T.ci.size() * 4 + 4); L.Tval = reserve(L.T.val.size() * 8 + 8);
         L.Qrp = reserve((n + 1) * 4); L.Qci = reserve(L.Q.ci.size() * 4 + 4); L.Qval = reserve(L.Q.val.size() * 8 + 8);
         L.q = reserve(n * 8); L.l = reserve(m * 8 + 8); L.u = reserve(m * 8 + 8);
         L.x0 = items[i].x0 ? reserve(n * 8) : (size_t)-1; L.y0 = items[i].y0 ? reserve(m * 8 + 8) : (size_t)-1;
+    }
+    lap("conversions");
+    const size_t upload_bytes = total;       // inputs
+    for (long i = 0; i < count; i++) {
+        const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
+        const size_t n = d->n, m = d->m;
         L.solx = reserve(n * 8); L.soly = reserve(m * 8 + 8); L.dx = reserve(n * 8); L.dy = reserve(m * 8 + 8);
     }
-    const size_t upload_bytes = total;       // everything above is input or output; the rest is scratch
+    const size_t out_bytes = total - upload_bytes;
     for (long i = 0; i < count; i++) {
         const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
         const size_t n = d->n, m = d->m;
         L.nv = reserve((size_t)NV_COUNT * n * 8); L.mv = reserve((size_t)MV_COUNT * m * 8 + 8); L.lsv = reserve(4 * m * 8 + 8);
         L.iv = reserve(3 * m * 4 + 4); L.K = reserve(n * n * 8);
     }
-    harena.assign(upload_bytes, 0);
-    for (long i = 0; i < count; i++) {
+    harena.reset(new char[upload_bytes ? upload_bytes : 1]); hout.reset(new char[out_bytes ? out_bytes : 1]);
+    parallel_items(count, [&](long i) {
         const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
         const size_t n = d->n, m = d->m;
-        char *h = harena.data();
+        char *h = harena.get();
+        const size_t reg_end = (i + 1 < count) ? lay[(size_t)i + 1].Arp : upload_bytes;     // this item's input region, padding included
+        memset(h + L.Arp, 0, reg_end - L.Arp);
         memcpy(h + L.Arp, L.A.rp.data(), (m + 1) * 4); if (!L.A.ci.empty()) { memcpy(h + L.Aci, L.A.ci.data(), L.A.ci.size() * 4); memcpy(h + L.Aval, L.A.val.data(), L.A.val.size() * 8); }
         memcpy(h + L.Trp, L.T.rp.data(), (n + 1) * 4); if (!L.T.ci.empty()) { memcpy(h + L.Tci, L.T.ci.data(), L.T.ci.size() * 4); memcpy(h + L.Tval, L.T.val.data(), L.T.val.size() * 8); }
         memcpy(h + L.Qrp, L.Q.rp.data(), (n + 1) * 4); if (!L.Q.ci.empty()) { memcpy(h + L.Qci, L.Q.ci.data(), L.Q.ci.size() * 4); memcpy(h + L.Qval, L.Q.val.data(), L.Q.val.size() * 8); }
         memcpy(h + L.q, d->q, n * 8); if (m) { memcpy(h + L.l, d->l, m * 8); memcpy(h + L.u, d->u, m * 8); }
         if (items[i].x0) memcpy(h + L.x0, items[i].x0, n * 8);
         if (items[i].y0 && m) memcpy(h + L.y0, items[i].y0, m * 8);
-    }
+    });
+    lap("staging fill");
     SHIP(hipSetDevice(device));
     SHIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    SHIP(hipMalloc((void **)&dbase, total));
+    if (s_arena && (s_arena_dev != device || s_arena_cap < total)) { (void)hipFree(s_arena); s_arena = nullptr; s_arena_cap = 0; }
+    if (!s_arena) { SHIP(hipMalloc((void **)&s_arena, total)); s_arena_cap = total; s_arena_dev = device; }
+    dbase = s_arena;
     SHIP(hipMalloc((void **)&dprobs, (size_t)count * sizeof(SmallQP)));
-    SHIP(hipMemcpyAsync(dbase, harena.data(), upload_bytes, hipMemcpyHostToDevice, stream));
+    lap("hipMalloc");
+    SHIP(hipMemcpyAsync(dbase, harena.get(), upload_bytes, hipMemcpyHostToDevice, stream));
+    if (tprof) { SHIP(hipStreamSynchronize(stream)); lap("upload"); }
     for (long i = 0; i < count; i++) {
         const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i]; SmallQP &p = hp[(size_t)i];
         memset(&p, 0, sizeof(p));
@@ -768,8 +817,10 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
     }
     SHIP(hipGetLastError());
     SHIP(hipMemcpyAsync(hp.data(), dprobs, (size_t)count * sizeof(SmallQP), hipMemcpyDeviceToHost, stream));
-    SHIP(hipMemcpyAsync(harena.data(), dbase, upload_bytes, hipMemcpyDeviceToHost, stream));
+    if (tprof) { SHIP(hipStreamSynchronize(stream)); lap("kernel"); }
+    SHIP(hipMemcpyAsync(hout.get(), dbase + upload_bytes, out_bytes, hipMemcpyDeviceToHost, stream));
     SHIP(hipStreamSynchronize(stream));
+    lap("download");
     if (dprof) {   // diagnostic: phase shares of the longest-running item
         std::vector<long long> hpf((size_t)count * PH_COUNT);
         SHIP(hipMemcpy(hpf.data(), dprof, hpf.size() * sizeof(long long), hipMemcpyDeviceToHost));
@@ -785,13 +836,13 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
         const size_t n = d->n, m = d->m;
         items[i].info = hp[(size_t)i].info;
         const long stv = items[i].info.status_val;
-        const double *sx = (const double *)(harena.data() + L.solx), *sy = (const double *)(harena.data() + L.soly);
+        const double *sx = (const double *)(hout.get() + (L.solx - upload_bytes)), *sy = (const double *)(hout.get() + (L.soly - upload_bytes));
         const bool infeasible = (stv == QPDO_PRIMAL_INFEASIBLE) || (stv == QPDO_DUAL_INFEASIBLE);
         if (items[i].x) for (size_t k = 0; k < n; k++) items[i].x[k] = infeasible ? NAN : sx[k];
         if (items[i].y) for (size_t k = 0; k < m; k++) items[i].y[k] = infeasible ? NAN : sy[k];
     }
+    lap("unpack");
 done:
-    if (dbase) (void)hipFree(dbase);
     if (dprobs) (void)hipFree(dprobs);
     if (dprof) (void)hipFree(dprof);
     if (stream) (void)hipStreamDestroy(stream);

@@ -347,36 +347,47 @@ def solve_problem(prob, settings=None, **kw):
     return res
 
 
+class Batch:
+    """Host-side image of a batch of independent QPs for qpdo_amd_solve_batch (ctypes structs + the arrays they point
+    to).  Building it is Python/scipy work; `run()` is the C call alone and may be repeated."""
+
+    def __init__(self, probs):
+        self.keep, self.items, self.outs = [], (BatchItem * len(probs))(), []
+        for i, p in enumerate(probs):
+            A, Q = sp.csc_matrix(p["A"]), sp.csc_matrix(p["Q"])
+            m, n = A.shape
+            q = np.ascontiguousarray(p["q"], np.float64)
+            l = np.clip(np.ascontiguousarray(p["l"], np.float64), -QPDO_INFTY, QPDO_INFTY)
+            u = np.clip(np.ascontiguousarray(p["u"], np.float64), -QPDO_INFTY, QPDO_INFTY)
+            Qs, As = _sparse_view(Q, p.get("Qstype", -1), self.keep), _sparse_view(A, 0, self.keep)
+            data = QPDOData()
+            data.n, data.m, data.Q, data.A = n, m, C.pointer(Qs), C.pointer(As)
+            data.q, data.c, data.l, data.u = _as_dp(q), float(p.get("c", 0.0)), _as_dp(l), _as_dp(u)
+            x, y = np.zeros(n), np.zeros(m)
+            self.keep.extend([q, l, u, Qs, As, data, x, y])
+            self.items[i].data = C.pointer(data)
+            self.items[i].x0, self.items[i].y0 = None, None
+            self.items[i].x, self.items[i].y = _as_dp(x), _as_dp(y)
+            self.outs.append((x, y))
+
+    def run(self, settings=None, nthreads=16, **kw):
+        if settings is None:
+            settings = default_settings(**kw)
+        failed = lib().qpdo_amd_solve_batch(len(self.outs), self.items, C.byref(settings), int(nthreads))
+        names = [f for f, _ in QPDOInfo._fields_]
+        res = []
+        for i, (x, y) in enumerate(self.outs):
+            inf = self.items[i].info
+            info = {f: getattr(inf, f) for f in names}
+            info["status"] = info["status"].decode()
+            res.append(dict(info=info, x=x.copy(), y=y.copy()))
+        return res, int(failed)
+
+
 def solve_batch(probs, settings=None, nthreads=16, **kw):
     """Solve independent QPs (dicts from qpdo_amd.problems) concurrently on this process's GPU.
-    Returns a list of dicts (info, x, y)."""
-    if settings is None:
-        settings = default_settings(**kw)
-    keep, items = [], (BatchItem * len(probs))()
-    outs = []
-    for i, p in enumerate(probs):
-        A, Q = sp.csc_matrix(p["A"]), sp.csc_matrix(p["Q"])
-        m, n = A.shape
-        q = np.ascontiguousarray(p["q"], np.float64)
-        l = np.clip(np.ascontiguousarray(p["l"], np.float64), -QPDO_INFTY, QPDO_INFTY)
-        u = np.clip(np.ascontiguousarray(p["u"], np.float64), -QPDO_INFTY, QPDO_INFTY)
-        Qs, As = _sparse_view(Q, p.get("Qstype", -1), keep), _sparse_view(A, 0, keep)
-        data = QPDOData()
-        data.n, data.m, data.Q, data.A = n, m, C.pointer(Qs), C.pointer(As)
-        data.q, data.c, data.l, data.u = _as_dp(q), float(p.get("c", 0.0)), _as_dp(l), _as_dp(u)
-        x, y = np.zeros(n), np.zeros(m)
-        keep.extend([q, l, u, Qs, As, data, x, y])
-        items[i].data = C.pointer(data)
-        items[i].x0, items[i].y0 = None, None
-        items[i].x, items[i].y = _as_dp(x), _as_dp(y)
-        outs.append((x, y))
-    failed = lib().qpdo_amd_solve_batch(len(probs), items, C.byref(settings), int(nthreads))
-    res = []
-    for i, (x, y) in enumerate(outs):
-        info = {f: getattr(items[i].info, f) for f, _ in QPDOInfo._fields_}
-        info["status"] = info["status"].decode()
-        res.append(dict(info=info, x=x, y=y))
-    return res, int(failed)
+    Returns a list of dicts (info, x, y) and the number of failed items."""
+    return Batch(probs).run(settings, nthreads, **kw)
 
 
 # ---- one large QP row-partitioned over the ranks of a torch.distributed job ---------------------------------
