@@ -340,11 +340,14 @@ __device__ void small_status(QPDOInfo &info, long st) {
 }
 
 // ---- the whole solve of one QP by one workgroup ----------------------------------------------------------
-__global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int count, QPDOSettings st, int klds_ok) {
+__global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, int count, QPDOSettings st, int klds_ok) {
     __shared__ double sm[32];
-    __shared__ u64 skey[2 * SM_MAX_M];
-    __shared__ u32 sidx[2 * SM_MAX_M];
-    extern __shared__ __attribute__((aligned(16))) double dyn[];      // [xs: n][colbuf: n][tk: 2n][ls_delta: 2m][ls_alpha: 2m][jflag: 2m bytes][K packed, if it fits]
+    // dynamic LDS: [xs: n][colbuf: n][tk: 2n][gbuf][d_s: m][rp_s: m+1][U], U = one region shared by the packed factor K
+    // (if it fits) and the linesearch scratch (delta, alpha, sort keys, sort indices, flags).  The linesearch of a
+    // pass runs after the pass's solve, so it may overwrite K: the factor is then rebuilt in the next pass instead
+    // of being reused when the weights did not change -- the same bits, a little more work -- and the workgroup needs
+    // ~67 KB instead of ~104 KB at n = 120, m = 360: two workgroups per CU instead of one.
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
     if ((int)blockIdx.x >= count) return;
     SmallQP &P = probs[blockIdx.x];
     const int n = P.n, m = P.m;
@@ -358,11 +361,15 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
            *res_prim_old = V[MV_RPOLD], *res_prim_in = V[MV_RPI], *dy = V[MV_DY], *Adx = V[MV_ADX], *dw = V[MV_DW], *E = V[MV_E],
            *Einv = V[MV_EINV], *ats = V[MV_ATS], *tm = V[MV_T];
     int *active = P.iv, *active_old = P.iv + m, *changed = P.iv + 2 * m;
-    double *xs = dyn, *colbuf = dyn + n, *tk = dyn + 2 * (size_t)n, *gbuf = dyn + 4 * (size_t)n, *ls_delta = gbuf + (((size_t)(n > m ? n : m) / 4 + 4 + 1) & ~(size_t)1), *ls_alpha = ls_delta + 2 * (size_t)m;
-    unsigned char *jflag = (unsigned char *)(ls_alpha + 2 * (size_t)m);
-    double *d_s = (double *)(jflag + (((size_t)2 * m + 15) & ~(size_t)15));
+    double *xs = dyn, *colbuf = dyn + n, *tk = dyn + 2 * (size_t)n, *gbuf = dyn + 4 * (size_t)n;
+    double *d_s = gbuf + (((size_t)(n > m ? n : m) / 4 + 4 + 1) & ~(size_t)1);
     int *rp_s = (int *)(d_s + m);
-    double *Klds = (double *)(rp_s + (((size_t)m + 1 + 3) & ~(size_t)3));
+    double *Klds = (double *)(rp_s + (((size_t)m + 1 + 3) & ~(size_t)3));          // start of U
+    double *ls_delta = Klds, *ls_alpha = ls_delta + 2 * (size_t)m;
+    size_t np2s = 1; while (np2s < 2 * (size_t)m) np2s <<= 1;                         // the bitonic sort pads 2m to a power of two
+    u64 *skey = (u64 *)(ls_alpha + 2 * (size_t)m);
+    u32 *sidx = (u32 *)(skey + np2s);
+    unsigned char *jflag = (unsigned char *)(sidx + np2s);
     KView kv; kv.n = n; kv.packed = klds_ok; kv.K = klds_ok ? Klds : P.K;
     const int scaled = st.scaling > 0, prox = (int)st.proximal;
     double sc_c = 1.0, sc_cinv = 1.0;
@@ -589,6 +596,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_small_solve(SmallQP *probs, int 
             SYNC;
             PH(PH_SPMV);
             tau = small_linesearch(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf);
+            if (klds_ok) factor_valid = 0;           // the scratch above lives in the factor's LDS region
             PH(PH_LS);
             FOR_T(j, n) { x[j] = x[j] + tau * dx[j]; Qx[j] = Qx[j] + tau * Qdx[j]; Aty[j] = Aty[j] + tau * Atdy[j]; }
             FOR_T(i, m) { y[i] = y[i] + tau * dy[i]; Ax[i] = Ax[i] + tau * Adx[i]; }
@@ -807,12 +815,16 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
     {
         size_t nmax = 1, mmax = 0;
         for (long i = 0; i < count; i++) { if (items[i].data->n > nmax) nmax = items[i].data->n; if (items[i].data->m > mmax) mmax = items[i].data->m; }
-        size_t lds = 4 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + 4 * mmax * 8 + ((2 * mmax + 15) & ~(size_t)15) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
+        size_t lds = 4 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
         const size_t kbytes = nmax * (nmax + 1) / 2 * 8;
-        const size_t budget = 160 * 1024 - 26 * 1024;          // static LDS: sort keys + indices + scratch
-        const int klds_ok = (lds + kbytes <= budget) ? 1 : 0;
-        if (klds_ok) lds += kbytes;
+        size_t np2 = 1; while (np2 < 2 * mmax) np2 <<= 1;
+        const size_t lsbytes = 2 * mmax * (8 + 8) + np2 * (8 + 4) + ((2 * mmax + 15) & ~(size_t)15);   // delta, alpha, keys, indices, flags
+        const size_t budget = 160 * 1024 - 1024;                // static LDS: reduction scratch only
+        int klds_ok = (lds + (kbytes > lsbytes ? kbytes : lsbytes) <= budget) ? 1 : 0;
+        if (const char *kg = getenv("QPDO_SMALL_K_GLOBAL")) { if (atoi(kg)) klds_ok = 0; }      // occupancy experiments
+        lds += (klds_ok && kbytes > lsbytes) ? kbytes : lsbytes;
         SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(budget)));
+        if (const char *pad = getenv("QPDO_SMALL_LDS_MIN")) { const size_t v = (size_t)atol(pad); if (v > lds && v <= budget) lds = v; }   // occupancy experiments
         hipLaunchKernelGGL(k_small_solve, dim3((unsigned)count), dim3(SM_THREADS), lds, stream, dprobs, (int)count, *settings, klds_ok);
     }
     SHIP(hipGetLastError());
