@@ -213,10 +213,25 @@ __device__ __forceinline__ void small_factor_t(int n, double *__restrict__ K, do
             K[offk + i] = l; lcol[i] = l; tcol[i] = l * dk;
         }
         SYNC;
-        for (int j = k + 1 + wj; j < n; j += nw) {
-            const double tj = tcol[j];
-            const int offj = PACKED ? j * n - (j * (j + 1)) / 2 : j * n;
-            for (int i = k + 1 + li; i < n; i += 64) if (i >= j) K[offj + i] -= lcol[i] * tj;
+        // four columns of the trailing triangle per trip: the LDS reads of all four are issued before the first
+        // dependent multiply (each element still receives exactly  K(i,j) -= l_ik * (l_jk d_k):  same bits)
+        for (int j0 = k + 1 + wj; j0 < n; j0 += 4 * nw) {
+            int jj[4], off[4]; double tj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                jj[u] = j0 + u * nw;
+                const int jc = jj[u] < n ? jj[u] : n - 1;
+                tj[u] = tcol[jc];
+                off[u] = PACKED ? jc * n - (jc * (jc + 1)) / 2 : jc * n;
+            }
+            for (int i = k + 1 + li; i < n; i += 64) {
+                const double a = lcol[i];
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = (jj[u] < n && i >= jj[u]) ? K[off[u] + i] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (jj[u] < n && i >= jj[u]) K[off[u] + i] = v[u] - a * tj[u];
+            }
         }
         SYNC;
         offk += PACKED ? n - k - 1 : n;
@@ -457,13 +472,17 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
                     if (eps != 0) {
                         if (scaled) { FOR_T(j, n) Atdy[j] = Dinv[j] * Atdy[j]; }
                         SYNC;
+                        // the 2m terms in parallel into LDS (the union region is free between passes), then one lane adds
+                        // them in the reference's order: a serial loop over global memory cost ~0.2 ms per outer update
+                        FOR_T(i, m) {
+                            const double e = scaled ? E[i] : 1.0;
+                            ls_delta[2 * i] = (P.u[i] < e * SM_INFTY) ? P.u[i] * s_max(dy[i], 0) : 0;
+                            ls_delta[2 * i + 1] = (P.l[i] > -e * SM_INFTY) ? P.l[i] * s_min(dy[i], 0) : 0;
+                        }
+                        SYNC;
                         if (threadIdx.x == 0) {
                             double oob = 0;
-                            for (int i = 0; i < m; i++) {
-                                const double e = scaled ? E[i] : 1.0;
-                                oob += (P.u[i] < e * SM_INFTY) ? P.u[i] * s_max(dy[i], 0) : 0;
-                                oob += (P.l[i] > -e * SM_INFTY) ? P.l[i] * s_min(dy[i], 0) : 0;
-                            }
+                            for (int i = 0; i < 2 * m; i++) oob += ls_delta[i];
                             sm[18] = oob;
                         }
                         SYNC;
