@@ -39,6 +39,7 @@ def parse():
                          "rows of A are partitioned over the GPUs with an RCCL all-reduce per A' product (strong scaling)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="bound of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the informational C2 / C3-batch measurements")
     ap.add_argument("--no-mixed-extra", action="store_true", help="skip the informational fp32-inner-preconditioner solve")
     return ap.parse_args()
 
@@ -251,6 +252,29 @@ def main():
             out["extra_fp32_inner_preconditioner"] = dict(error=repr(e))
         finally:
             os.environ.pop("QPDO_PCG_INNER_F32", None)
+    if rank == 0 and world == 1 and a.workload == "C4" and not a.no_other_configs:
+        # Informational extras, NOT part of `value`: the other single-GPU configurations of BASELINE.json, measured in the
+        # same process (configs[1]: one QP n=1e4, m=2e4; configs[2]: 4096 MPC-sized QPs through the fused batch kernel).
+        try:
+            p2 = problems.config_qp("C2")
+            t0 = time.time(); s3 = solver.QPDO().setup(p2["Q"], p2["q"], p2["A"], p2["l"], p2["u"], Qstype=-1, verbose=0); ts = time.time() - t0
+            t0 = time.time(); r3 = s3.solve(); L.qpdo_amd_sync(s3._w); dt3 = time.time() - t0
+            st3 = s3.stats(); s3.delete()
+            out["other_configs"] = {"C2": dict(workload="n=10000, m=20000, density 0.01, cold start, default settings", time_to_eps_s=dt3, setup_s=ts,
+                                               newton_iters_per_s=st3["newton_passes"] / dt3, status_val=r3["info"]["status_val"],
+                                               iterations=r3["info"]["iterations"], linsolve="dense-ldlt" if st3["linsolve"] == 1 else "pcg",
+                                               factor_count=st3["factor_count"], lowrank_solves=st3["lowrank_solves"])}
+            nb = 4096
+            probs = [problems.config_qp("C3", i) for i in range(nb)]
+            B = solver.Batch(probs)
+            B.run(verbose=0, max_iter=300)                      # warm-up (device arena, code objects)
+            t0 = time.time(); resb, failed = B.run(verbose=0, max_iter=300); dtb = time.time() - t0
+            out["other_configs"]["C3_batch"] = dict(workload="%d QPs n=120, m=360 (120 equality rows), one fused-kernel launch, max_iter=300" % nb,
+                                                    seconds=dtb, qps_per_s=nb / dtb, failed=failed,
+                                                    newton_iters_per_s=sum(r_["info"]["iterations"] - r_["info"]["oterations"] for r_ in resb) / dtb,
+                                                    solved=sum(r_["info"]["status_val"] == 1 for r_ in resb))
+        except Exception as e:
+            out.setdefault("other_configs", {})["error"] = repr(e)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
