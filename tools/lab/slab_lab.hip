@@ -267,10 +267,10 @@ __global__ void k_rebuild(int m, int per_row, int nslabs, int W, const int *__re
 }
 
 template <int TPR, int UNR, int NT>
-static void run_prod_wg(const char *name, int m, int n, int nwg, const int *sp0, int nslabs0, const unsigned short *ci16_rm, const int *ci_rm, const double *val_rm, const double *x, double *y, double nnz) {
+static void run_prod_wg(const char *name, int m, int n, int nwg, int budget_div, const int *sp0, int nslabs0, const unsigned short *ci16_rm, const int *ci_rm, const double *val_rm, const double *x, double *y, double nnz) {
     // rebuild slab tables for this (W, rows-per-wg): W from the LDS budget of one workgroup
     const int rpw = (m + nwg - 1) / nwg;
-    const int lds_budget = (NT == 1024 ? (160 * 1024 - 1024) : (80 * 1024 - 1024)) / 8 - rpw;
+    const int lds_budget = ((NT == 1024 ? (160 * 1024 - 1024) : (80 * 1024 - 1024)) / 8 - rpw) / budget_div;
     int nslabs = (n + lds_budget - 1) / lds_budget; int W = (((n + nslabs - 1) / nslabs) + 63) & ~63; if (W > lds_budget) { nslabs++; W = (((n + nslabs - 1) / nslabs) + 63) & ~63; }
     int *sp; int2 *seg; unsigned short *i16, *i16sm; double *vsm;
     CK(hipMalloc(&sp, (size_t)m * (nslabs + 1) * 4)); CK(hipMalloc(&seg, (size_t)m * nslabs * 8)); CK(hipMalloc(&i16, (size_t)nnz * 2)); CK(hipMalloc(&i16sm, ((size_t)nnz + 4) * 2)); CK(hipMalloc(&vsm, ((size_t)nnz + 4) * 8));
@@ -379,12 +379,14 @@ int main() {
     {   // compact-shaped product (k = 73000 active rows): workgroup geometry
         const int kk = 73000; const double nnzk = (double)kk * per_row;
         printf("compact shape k=%d\n", kk);
-        run_prod_wg<16, 8, 1024>("1024 thr, 1 wg/CU (production)", kk, n, 256, sp, nslabs, ci16, ci, val, x, y, nnzk);
-        run_prod_wg<16, 8, 512>("512 thr, 2 wg/CU", kk, n, 512, sp, nslabs, ci16, ci, val, x, y, nnzk);
-        run_prod_wg<16, 8, 512>("512 thr, 2 wg/CU, 1024 wgs", kk, n, 1024, sp, nslabs, ci16, ci, val, x, y, nnzk);
-        run_prod_wg<16, 8, 1024>("1024 thr, 512 wgs (2 waves of wgs)", kk, n, 512, sp, nslabs, ci16, ci, val, x, y, nnzk);
-        run_prod_wg<16, 8, 1024>("full m, production geometry", m, n, 256, sp, nslabs, ci16, ci, val, x, y, nnz);
-        run_prod_wg<16, 8, 512>("full m, 512 thr 2 wg/CU", m, n, 512, sp, nslabs, ci16, ci, val, x, y, nnz);
+        run_prod_wg<16, 8, 1024>("1024 thr, 1 wg/CU (production)", kk, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnzk);
+        run_prod_wg<16, 8, 1024>("1024 thr, half-size slabs (no overlap)", kk, n, 256, 2, sp, nslabs, ci16, ci, val, x, y, nnzk);
+        run_prod_wg<8, 8, 1024>("1024 thr, half-size slabs, tpr8", kk, n, 256, 2, sp, nslabs, ci16, ci, val, x, y, nnzk);
+        run_prod_wg<16, 8, 512>("512 thr, 2 wg/CU", kk, n, 512, 1, sp, nslabs, ci16, ci, val, x, y, nnzk);
+        run_prod_wg<16, 8, 512>("512 thr, 2 wg/CU, 1024 wgs", kk, n, 1024, 1, sp, nslabs, ci16, ci, val, x, y, nnzk);
+        run_prod_wg<16, 8, 1024>("1024 thr, 512 wgs (2 waves of wgs)", kk, n, 512, 1, sp, nslabs, ci16, ci, val, x, y, nnzk);
+        run_prod_wg<16, 8, 1024>("full m, production geometry", m, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnz);
+        run_prod_wg<16, 8, 512>("full m, 512 thr 2 wg/CU", m, n, 512, 1, sp, nslabs, ci16, ci, val, x, y, nnz);
     }
     // ---- slab-major storage: per workgroup, all row segments of slab 0, then of slab 1, ... (sequential stream per slab phase)
     {
