@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <thread>
 
 #include <rccl/rccl.h>
 
