@@ -41,6 +41,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef double  f64;
 typedef int64_t i64;
@@ -104,6 +107,7 @@ typedef struct {
     Csc Q, A;           /* scaled copies */
     /* row-access copies for assembly / PCG: CSR(A) and full symmetric CSR(Q) */
     i64 *Arp, *Aci; f64 *Arx; i64 *Amap;   /* Amap: CSR slot -> CSC slot */
+    i64 *Qrp, *Qci, *Qmap;                 /* full symmetric CSR pattern of Q (large n, lower storage only) */
     f64 *q, *l, *u; f64 c;
     OracleSettings s;
     /* scaling */
@@ -206,6 +210,7 @@ static void csc_mv(const Csc *M, const f64 *x, f64 *y) {
 }
 /* y = M' x, CSC general */
 static void csc_tmv(const Csc *M, const f64 *x, f64 *y) {
+#pragma omp parallel for schedule(static) if (M->p[M->ncol] > 200000)
     for (i64 j = 0; j < M->ncol; j++) {
         f64 s = 0.0;
         for (i64 k = M->p[j]; k < M->p[j+1]; k++) s += M->x[k] * x[M->i[k]];
@@ -256,6 +261,59 @@ static void build_csr_A(Oracle *o) {
 static void refresh_csr_A(Oracle *o) {
     i64 nnz = o->A.p[o->n];
     for (i64 s = 0; s < nnz; s++) o->Arx[s] = o->A.x[o->Amap[s]];
+}
+
+/* Row-gather forms of the two non-transposed products, used so that they can run on all cores.  Both give the
+ * SAME BITS as csc_mv: the column-ordered scatter adds the contributions to y_i in ascending column order, and a
+ * row gather over column-sorted rows performs the same additions in the same order (for the symmetric case the
+ * full row r is [columns j < r from the stored triangle] ++ [stored column r from the diagonal down]). */
+static void A_mv(const Oracle *o, const f64 *x, f64 *y) {
+    if (!o->Arp || o->A.p[o->n] <= 200000) { csc_mv(&o->A, x, y); return; }
+#pragma omp parallel for schedule(static)
+    for (i64 r = 0; r < o->m; r++) {
+        f64 s = 0.0;
+        for (i64 a = o->Arp[r]; a < o->Arp[r+1]; a++) s += o->Arx[a] * x[o->Aci[a]];
+        y[r] = s;
+    }
+}
+static void build_csr_Q(Oracle *o) {
+    i64 n = o->n;
+    if (o->Q.stype >= 0 || o->Q.p[n] <= 100000) return;
+    for (i64 j = 0; j < n; j++)                 /* needs sorted columns */
+        for (i64 k = o->Q.p[j] + 1; k < o->Q.p[j+1]; k++) if (o->Q.i[k] <= o->Q.i[k-1]) return;
+    i64 *rp = ivec(n + 1);
+    for (i64 j = 0; j < n; j++)
+        for (i64 k = o->Q.p[j]; k < o->Q.p[j+1]; k++) {
+            i64 i = o->Q.i[k];
+            if (i > j) { rp[i+1]++; rp[j+1]++; } else if (i == j) rp[j+1]++;
+        }
+    for (i64 i = 0; i < n; i++) rp[i+1] += rp[i];
+    i64 nz = rp[n];
+    i64 *ci = ivec(nz), *mp = ivec(nz), *next = ivec(n);
+    for (i64 i = 0; i < n; i++) next[i] = rp[i];
+    /* pass 1: strictly-lower entries as (row i, column j), columns ascending because j ascends */
+    for (i64 j = 0; j < n; j++)
+        for (i64 k = o->Q.p[j]; k < o->Q.p[j+1]; k++) {
+            i64 i = o->Q.i[k];
+            if (i > j) { i64 s = next[i]++; ci[s] = j; mp[s] = k; }
+        }
+    /* pass 2: stored column j from the diagonal down = row j, columns i >= j ascending */
+    for (i64 j = 0; j < n; j++)
+        for (i64 k = o->Q.p[j]; k < o->Q.p[j+1]; k++) {
+            i64 i = o->Q.i[k];
+            if (i >= j) { i64 s = next[j]++; ci[s] = i; mp[s] = k; }
+        }
+    free(next);
+    o->Qrp = rp; o->Qci = ci; o->Qmap = mp;
+}
+static void Q_mv(const Oracle *o, const f64 *x, f64 *y) {
+    if (!o->Qrp) { csc_mv(&o->Q, x, y); return; }
+#pragma omp parallel for schedule(static)
+    for (i64 r = 0; r < o->n; r++) {
+        f64 s = 0.0;
+        for (i64 a = o->Qrp[r]; a < o->Qrp[r+1]; a++) s += o->Q.x[o->Qmap[a]] * x[o->Qci[a]];
+        y[r] = s;
+    }
 }
 
 /* ---- scaling (scaling.c:13-91) -------------------------------------------- */
@@ -371,7 +429,7 @@ Oracle *oracle_setup(i64 n, i64 m,
     } else {
         o->norm_q = vec_norm_inf(o->q, n);
     }
-    build_csr_A(o); refresh_csr_A(o);
+    build_csr_A(o); refresh_csr_A(o); build_csr_Q(o);
     o->status_val = ST_UNSOLVED;
     o->setup_time = now_s() - t0;
     return o;
@@ -434,10 +492,10 @@ void oracle_warm_start(Oracle *o, const f64 *xw, const f64 *yw) {
         if (o->scaled) vec_ew_prod(o->x, o->Dinv, o->x, n);
         memcpy(o->xbar, o->x, (size_t)n * sizeof(f64));
         memcpy(o->dx, o->x, (size_t)n * sizeof(f64));
-        csc_mv(&o->Q, o->dx, o->Qdx);
+        Q_mv(o, o->dx, o->Qdx);
         if (o->s.proximal) vec_add_scaled(o->Qdx, o->x, o->Qx, o->sigma, n);
         else memcpy(o->Qx, o->Qdx, (size_t)n * sizeof(f64));
-        csc_mv(&o->A, o->dx, o->Adx);
+        A_mv(o, o->dx, o->Adx);
         memcpy(o->Ax, o->Adx, (size_t)m * sizeof(f64));
         o->objective = compute_objective(o);
     } else {
@@ -518,36 +576,30 @@ static void compute_inner_residuals_norm(Oracle *o) {
 }
 
 /* ---- linear system K = Q + sigma_f I + A' diag(d) A ----------------------- */
-static void assemble_and_factor(Oracle *o) {
-    i64 n = o->n, m = o->m;
-    if (!o->K) o->K = (f64 *)malloc((size_t)n * (size_t)n * sizeof(f64));
-    f64 *K = o->K;
-    memset(K, 0, (size_t)n * (size_t)n * sizeof(f64));
-    /* lower triangle of Q (either stored triangle, or lower part of full storage) */
-    for (i64 j = 0; j < n; j++)
-        for (i64 k = o->Q.p[j]; k < o->Q.p[j+1]; k++) {
-            i64 i = o->Q.i[k];
-            if (o->Q.stype < 0)      { if (i >= j) K[i + j*n] += o->Q.x[k]; }
-            else if (o->Q.stype > 0) { if (i <= j) K[j + i*n] += o->Q.x[k]; }
-            else                     { if (i >= j) K[i + j*n] += o->Q.x[k]; }
-        }
-    for (i64 r = 0; r < m; r++) {
-        f64 dr = o->d[r];
-        if (dr == 0.0) continue;
-        for (i64 a = o->Arp[r]; a < o->Arp[r+1]; a++) {
-            i64 j = o->Aci[a]; f64 vj = o->Arx[a] * dr;
-            for (i64 b = a; b < o->Arp[r+1]; b++)      /* columns ascending: Aci[b] >= j */
-                K[o->Aci[b] + j*n] += vj * o->Arx[b];
-        }
-    }
-    for (i64 j = 0; j < n; j++) K[j + j*n] += o->sigma_f;
-    /* dense LDL', natural order, no pivoting (cholmod_interface.c:107-123: NATURAL,
-     * no postorder; result kept as LDL').  Left-looking by columns. */
+/*
+ * Dense LDL', natural order, no pivoting (cholmod_interface.c:107-123: NATURAL, no postorder;
+ * result kept as LDL').  Two implementations with IDENTICAL results bit for bit:
+ *   ldl_factor_scalar  -- the plain left-looking column loop (the definition);
+ *   ldl_factor_blocked -- right-looking over panels of LDL_NB columns, OpenMP over tiles.
+ * Every entry (i,j) of both receives  K_ij -= L_ik * (L_jk * D_k)  for k = 0, 1, .., j-1 in ascending
+ * order, each product and each subtraction rounded separately (no FMA: -ffp-contract=off), then
+ * L_ij = K_ij * (1/D_j); only the order in which *different* entries are visited differs.  The blocked
+ * version exists so that the oracle can produce fixtures at production sizes (n = 1e4 .. 3e4) and serve as
+ * the all-cores CPU baseline; tests/test_oracle_specs.py checks the bitwise equality.
+ */
+#define LDL_NB 256
+#define LDL_MR 24
+#define LDL_NR 8
+#define LDL_TR 10     /* micro row blocks per task: 240 rows */
+#define LDL_TC 16     /* micro column blocks per task: 128 columns */
+static int g_ldl_force_scalar = 0;
+void oracle_set_ldl_scalar(int on) { g_ldl_force_scalar = on; }
+
+static void ldl_factor_scalar(f64 *K, i64 n) {
     for (i64 j = 0; j < n; j++) {
         f64 *cj = K + j*n;
         for (i64 k = 0; k < j; k++) {
             f64 ljk = K[j + k*n];
-            if (ljk == 0.0) continue;
             f64 t = ljk * K[k + k*n];          /* L_jk * D_k */
             const f64 *ck = K + k*n;
             for (i64 i = j; i < n; i++) cj[i] -= ck[i] * t;
@@ -555,6 +607,190 @@ static void assemble_and_factor(Oracle *o) {
         f64 inv = 1.0 / cj[j];
         for (i64 i = j + 1; i < n; i++) cj[i] *= inv;
     }
+}
+
+#include <immintrin.h>
+/* C[MR x NR] (column-major, leading dimension ldc) -= sum_k a[k][0..MR) * w[k][0..NR), k ascending, one rounding
+ * per multiply and per subtract (separate vmulpd / vsubpd: this file is compiled with -ffp-contract=off).
+ * a and w are packed k-major.  rows/cols: how much of the tile exists; tri: store only entries with
+ * (i0 + r) >= (j0 + c). */
+#define LDL_COL(c) \
+    b = _mm512_set1_pd(wk[c]); \
+    c0##c = _mm512_sub_pd(c0##c, _mm512_mul_pd(a0, b)); \
+    c1##c = _mm512_sub_pd(c1##c, _mm512_mul_pd(a1, b)); \
+    c2##c = _mm512_sub_pd(c2##c, _mm512_mul_pd(a2, b));
+#define LDL_LD(c) c0##c = _mm512_loadu_pd(src + (c)*ld); c1##c = _mm512_loadu_pd(src + (c)*ld + 8); c2##c = _mm512_loadu_pd(src + (c)*ld + 16);
+#define LDL_ST(c) _mm512_storeu_pd(dst + (c)*ld, c0##c); _mm512_storeu_pd(dst + (c)*ld + 8, c1##c); _mm512_storeu_pd(dst + (c)*ld + 16, c2##c);
+__attribute__((target("avx512f")))
+static void ldl_tile_avx512(f64 *C, i64 ldc, const f64 *a, const f64 *w, i64 kk, i64 rows, i64 cols,
+                            int tri, i64 i0, i64 j0) {
+    __m512d c00, c10, c20, c01, c11, c21, c02, c12, c22, c03, c13, c23, c04, c14, c24, c05, c15, c25,
+            c06, c16, c26, c07, c17, c27, a0, a1, a2, b;
+    f64 tmp[LDL_MR * LDL_NR];
+    int full = (rows == LDL_MR && cols == LDL_NR && !tri);
+    const f64 *src; f64 *dst; i64 ld;
+    if (full) { src = C; ld = ldc; }
+    else {
+        memset(tmp, 0, sizeof tmp);
+        for (i64 c = 0; c < cols; c++) for (i64 r = 0; r < rows; r++) tmp[c*LDL_MR + r] = C[c*ldc + r];
+        src = tmp; ld = LDL_MR;
+    }
+    LDL_LD(0) LDL_LD(1) LDL_LD(2) LDL_LD(3) LDL_LD(4) LDL_LD(5) LDL_LD(6) LDL_LD(7)
+    for (i64 k = 0; k < kk; k++) {
+        const f64 *ak = a + k*LDL_MR, *wk = w + k*LDL_NR;
+        a0 = _mm512_loadu_pd(ak); a1 = _mm512_loadu_pd(ak + 8); a2 = _mm512_loadu_pd(ak + 16);
+        LDL_COL(0) LDL_COL(1) LDL_COL(2) LDL_COL(3) LDL_COL(4) LDL_COL(5) LDL_COL(6) LDL_COL(7)
+    }
+    if (full) { dst = C; LDL_ST(0) LDL_ST(1) LDL_ST(2) LDL_ST(3) LDL_ST(4) LDL_ST(5) LDL_ST(6) LDL_ST(7) }
+    else {
+        dst = tmp; LDL_ST(0) LDL_ST(1) LDL_ST(2) LDL_ST(3) LDL_ST(4) LDL_ST(5) LDL_ST(6) LDL_ST(7)
+        for (i64 c = 0; c < cols; c++) for (i64 r = 0; r < rows; r++)
+            if (!tri || (i0 + r) >= (j0 + c)) C[c*ldc + r] = tmp[c*LDL_MR + r];
+    }
+}
+static void ldl_tile_generic(f64 *C, i64 ldc, const f64 *a, const f64 *w, i64 kk, i64 rows, i64 cols,
+                             int tri, i64 i0, i64 j0) {
+    for (i64 c = 0; c < cols; c++) {
+        i64 r0 = 0;
+        if (tri && (j0 + c) > i0) r0 = (j0 + c) - i0;
+        for (i64 r = r0; r < rows; r++) {
+            f64 v = C[c*ldc + r];
+            for (i64 k = 0; k < kk; k++) v -= a[k*LDL_MR + r] * w[k*LDL_NR + c];
+            C[c*ldc + r] = v;
+        }
+    }
+}
+
+static void ldl_factor_blocked(f64 *K, i64 n) {
+    int use512 = __builtin_cpu_supports("avx512f");
+    i64 nrb_max = (n + LDL_MR - 1) / LDL_MR, ncb_max = (n + LDL_NR - 1) / LDL_NR;
+    f64 *Apack = (f64 *)malloc((size_t)nrb_max * LDL_MR * LDL_NB * sizeof(f64));
+    f64 *Wpack = (f64 *)malloc((size_t)ncb_max * LDL_NR * LDL_NB * sizeof(f64));
+    f64 *T = (f64 *)malloc((size_t)LDL_NB * LDL_NB * sizeof(f64));   /* T[j][k] = L_jk * D_k inside the panel */
+    for (i64 p0 = 0; p0 < n; p0 += LDL_NB) {
+        i64 nb = MINV((i64)LDL_NB, n - p0), p1 = p0 + nb;
+        /* 1. diagonal block: the scalar recurrence restricted to rows/columns [p0, p1) */
+        for (i64 j = p0; j < p1; j++) {
+            f64 *cj = K + j*n;
+            for (i64 k = p0; k < j; k++) {
+                f64 t = K[j + k*n] * K[k + k*n];
+                T[(j - p0)*LDL_NB + (k - p0)] = t;
+                const f64 *ck = K + k*n;
+                for (i64 i = j; i < p1; i++) cj[i] -= ck[i] * t;
+            }
+            f64 inv = 1.0 / cj[j];
+            for (i64 i = j + 1; i < p1; i++) cj[i] *= inv;
+        }
+        if (p1 >= n) break;
+        /* 2. rows below the panel: the same recurrence row by row (rows are independent) */
+        i64 below = n - p1;
+#pragma omp parallel for schedule(dynamic, 1) if (below * nb > 20000)
+        for (i64 c0 = 0; c0 < below; c0 += 128) {
+            i64 r0 = p1 + c0, r1 = MINV(n, r0 + 128);
+            for (i64 j = p0; j < p1; j++) {
+                f64 *cj = K + j*n;
+                for (i64 k = p0; k < j; k++) {
+                    f64 t = T[(j - p0)*LDL_NB + (k - p0)];
+                    const f64 *ck = K + k*n;
+                    for (i64 i = r0; i < r1; i++) cj[i] -= ck[i] * t;
+                }
+                f64 inv = 1.0 / cj[j];
+                for (i64 i = r0; i < r1; i++) cj[i] *= inv;
+            }
+        }
+        /* 3. pack L (rows below, k-major per block of MR rows) and W = L * D (k-major per block of NR columns) */
+        i64 nrb = (below + LDL_MR - 1) / LDL_MR, ncb = (below + LDL_NR - 1) / LDL_NR;
+#pragma omp parallel for schedule(static) if (below * nb > 20000)
+        for (i64 b = 0; b < nrb; b++) {
+            f64 *dst = Apack + (size_t)b * LDL_MR * nb;
+            i64 r0 = p1 + b*LDL_MR;
+            for (i64 k = 0; k < nb; k++)
+                for (i64 r = 0; r < LDL_MR; r++)
+                    dst[k*LDL_MR + r] = (r0 + r < n) ? K[(r0 + r) + (p0 + k)*n] : 0.0;
+        }
+#pragma omp parallel for schedule(static) if (below * nb > 20000)
+        for (i64 b = 0; b < ncb; b++) {
+            f64 *dst = Wpack + (size_t)b * LDL_NR * nb;
+            i64 c0 = p1 + b*LDL_NR;
+            for (i64 k = 0; k < nb; k++)
+                for (i64 c = 0; c < LDL_NR; c++)
+                    dst[k*LDL_NR + c] = (c0 + c < n) ? K[(c0 + c) + (p0 + k)*n] * K[(p0 + k) + (p0 + k)*n] : 0.0;
+        }
+        /* 4. trailing update of the lower triangle: tasks of LDL_TR x LDL_TC micro-tiles (MR x NR each); inside a
+         *    task the W tile of a column block stays in L1 while the packed rows stream from L2 */
+        i64 ntr = (nrb + LDL_TR - 1) / LDL_TR, ntc = (ncb + LDL_TC - 1) / LDL_TC;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1) if (below * below * nb > 200000)
+        for (i64 tr = ntr - 1; tr >= 0; tr--)
+            for (i64 tc = 0; tc < ntc; tc++) {
+                i64 rb0 = tr * LDL_TR, rb1 = MINV(nrb, rb0 + LDL_TR);
+                i64 cb0 = tc * LDL_TC, cb1 = MINV(ncb, cb0 + LDL_TC);
+                i64 last_row = MINV(n, p1 + rb1*LDL_MR) - 1;
+                if (p1 + cb0*LDL_NR > last_row) continue;           /* task entirely above the diagonal */
+                for (i64 cb = cb0; cb < cb1; cb++) {
+                    i64 j0 = p1 + cb*LDL_NR, cols = MINV((i64)LDL_NR, n - j0);
+                    const f64 *w = Wpack + (size_t)cb * LDL_NR * nb;
+                    for (i64 rb = rb0; rb < rb1; rb++) {
+                        i64 i0 = p1 + rb*LDL_MR, rows = MINV((i64)LDL_MR, n - i0);
+                        if (j0 > i0 + rows - 1) continue;            /* tile entirely above the diagonal */
+                        int tri = (j0 + cols - 1) > i0;
+                        const f64 *a = Apack + (size_t)rb * LDL_MR * nb;
+                        f64 *C = K + i0 + j0*n;
+                        if (use512) ldl_tile_avx512(C, n, a, w, nb, rows, cols, tri, i0, j0);
+                        else ldl_tile_generic(C, n, a, w, nb, rows, cols, tri, i0, j0);
+                    }
+                }
+            }
+    }
+    free(Apack); free(Wpack); free(T);
+}
+
+static void assemble_and_factor(Oracle *o) {
+    i64 n = o->n, m = o->m;
+    if (!o->K) o->K = (f64 *)malloc((size_t)n * (size_t)n * sizeof(f64));
+    f64 *K = o->K;
+    /* every entry of K is built by one thread, contributions in the order of the serial loops (Q entry, then the
+     * weighted rows of A in ascending row order, then sigma_f): column ranges per thread */
+#pragma omp parallel if (n >= 512)
+    {
+        i64 nt = 1, tid = 0;
+#ifdef _OPENMP
+        nt = omp_get_num_threads(); tid = omp_get_thread_num();
+#endif
+        /* balance the triangle: column j has n-j rows */
+        i64 jlo = (i64)((f64)n * (1.0 - sqrt(1.0 - (f64)tid / (f64)nt)));
+        i64 jhi = (tid == nt - 1) ? n : (i64)((f64)n * (1.0 - sqrt(1.0 - (f64)(tid + 1) / (f64)nt)));
+        if (jlo > n) jlo = n;
+        if (jhi > n) jhi = n;
+        if (jhi > jlo) memset(K + jlo*n, 0, (size_t)(jhi - jlo) * (size_t)n * sizeof(f64));
+        /* lower triangle of Q (either stored triangle, or lower part of full storage) */
+        if (o->Q.stype > 0) {
+            for (i64 j = 0; j < n; j++)
+                for (i64 k = o->Q.p[j]; k < o->Q.p[j+1]; k++) {
+                    i64 i = o->Q.i[k];
+                    if (i <= j && i >= jlo && i < jhi) K[j + i*n] += o->Q.x[k];
+                }
+        } else {
+            for (i64 j = jlo; j < jhi; j++)
+                for (i64 k = o->Q.p[j]; k < o->Q.p[j+1]; k++) {
+                    i64 i = o->Q.i[k];
+                    if (i >= j) K[i + j*n] += o->Q.x[k];
+                }
+        }
+        for (i64 r = 0; r < m; r++) {
+            f64 dr = o->d[r];
+            if (dr == 0.0) continue;
+            i64 a0 = o->Arp[r], a1 = o->Arp[r+1], lo = a0, hi = a1;
+            while (lo < hi) { i64 mid = (lo + hi) / 2; if (o->Aci[mid] < jlo) lo = mid + 1; else hi = mid; }
+            for (i64 a = lo; a < a1 && o->Aci[a] < jhi; a++) {
+                i64 j = o->Aci[a]; f64 vj = o->Arx[a] * dr;
+                for (i64 b = a; b < a1; b++)      /* columns ascending: Aci[b] >= j */
+                    K[o->Aci[b] + j*n] += vj * o->Arx[b];
+            }
+        }
+        for (i64 j = jlo; j < jhi; j++) K[j + j*n] += o->sigma_f;
+    }
+    if (g_ldl_force_scalar || n < 512) ldl_factor_scalar(K, n);
+    else ldl_factor_blocked(K, n);
     o->factor_valid = 1; o->factor_dirty = 0;
 }
 static void ldl_solve(Oracle *o, const f64 *b, f64 *x) {
@@ -574,9 +810,10 @@ static void ldl_solve(Oracle *o, const f64 *b, f64 *x) {
 /* operator v -> K v using the row-access copies */
 static void K_apply(Oracle *o, const f64 *v, f64 *out) {
     i64 n = o->n, m = o->m;
-    csc_mv(&o->Q, v, out);
+    Q_mv(o, v, out);
     for (i64 i = 0; i < n; i++) out[i] += o->sigma_f * v[i];
     f64 *t = o->pc_t;
+#pragma omp parallel for schedule(static) if (o->A.p[n] > 200000)
     for (i64 r = 0; r < m; r++) {
         f64 s = 0.0;
         if (o->d[r] != 0.0) {
@@ -585,6 +822,7 @@ static void K_apply(Oracle *o, const f64 *v, f64 *out) {
         }
         t[r] = s;
     }
+#pragma omp parallel for schedule(static) if (o->A.p[n] > 200000)
     for (i64 j = 0; j < n; j++) {
         f64 s = 0.0;
         for (i64 k = o->A.p[j]; k < o->A.p[j+1]; k++) s += o->A.x[k] * t[o->A.i[k]];
@@ -601,6 +839,7 @@ static i64 pcg_solve(Oracle *o, const f64 *b, f64 *x) {
     for (i64 j = 0; j < n; j++) dg[j] = o->sigma_f;
     for (i64 j = 0; j < n; j++)
         for (i64 k = o->Q.p[j]; k < o->Q.p[j+1]; k++) if (o->Q.i[k] == j) dg[j] += o->Q.x[k];
+#pragma omp parallel for schedule(static) if (o->A.p[n] > 200000)
     for (i64 j = 0; j < n; j++) {
         f64 s = 0.0;
         for (i64 k = o->A.p[j]; k < o->A.p[j+1]; k++) s += o->A.x[k] * o->A.x[k] * o->d[o->A.i[k]];
@@ -681,9 +920,9 @@ static void newton_direction(Oracle *o, TraceRec *tr) {
         tr->lin_iters = pcg_solve(o, o->rhs, o->dx);
         o->lin_iters_total += tr->lin_iters;
     }
-    csc_mv(&o->Q, o->dx, o->Qdx);
+    Q_mv(o, o->dx, o->Qdx);
     if (o->s.proximal) vec_add_scaled(o->Qdx, o->dx, o->Qdx, o->sigma, n);
-    csc_mv(&o->A, o->dx, o->Adx);
+    A_mv(o, o->dx, o->Adx);
     for (i64 i = 0; i < m; i++) if (o->active[i]) o->dy[i] += (o->Adx[i] / o->mu[i]);
     csc_tmv(&o->A, o->dy, o->Atdy);
     memcpy(o->active_old, o->active, (size_t)m * sizeof(i64));
@@ -940,8 +1179,8 @@ void oracle_solve(Oracle *o) {
                 }
                 if (o->s.eps_dual_inf > 0) {
                     vec_add_scaled(o->x, o->xbar, o->dx, -1, n);
-                    csc_mv(&o->Q, o->dx, o->Qdx);
-                    csc_mv(&o->A, o->dx, o->Adx);
+                    Q_mv(o, o->dx, o->Qdx);
+                    A_mv(o, o->dx, o->Adx);
                     if (is_dual_infeasible(o)) break;
                 }
             }
@@ -1066,6 +1305,7 @@ void oracle_cleanup(Oracle *o) {
     if (!o) return;
     free(o->Q.p); free(o->Q.i); free(o->Q.x); free(o->A.p); free(o->A.i); free(o->A.x);
     free(o->Arp); free(o->Aci); free(o->Arx); free(o->Amap);
+    free(o->Qrp); free(o->Qci); free(o->Qmap);
     free(o->q); free(o->l); free(o->u); free(o->D); free(o->Dinv); free(o->E); free(o->Einv);
     free(o->x); free(o->y); free(o->Ax); free(o->Qx); free(o->Aty); free(o->xbar); free(o->ybar);
     free(o->temp_m); free(o->temp_n); free(o->temp_2m); free(o->mu); free(o->isq); free(o->At_scale);
@@ -1088,6 +1328,8 @@ void oracle_csc_mv(i64 nrow, i64 ncol, const i64 *p, const i64 *i, const f64 *x,
 }
 f64 oracle_vec_norm_inf(const f64 *a, i64 n) { return vec_norm_inf(a, n); }
 f64 oracle_vec_prod(const f64 *a, const f64 *b, i64 n) { return vec_prod(a, b, n); }
+/* in-place dense LDL' of a caller matrix (column-major, lower triangle used): the two implementations */
+void oracle_ldl_factor(f64 *K, i64 n, int blocked) { if (blocked) ldl_factor_blocked(K, n); else ldl_factor_scalar(K, n); }
 /* piecewise-affine root (linesearch.c:74-158) on caller data: returns tau */
 f64 oracle_pwa_linesearch(i64 m, f64 eta, f64 beta, const f64 *delta, const f64 *alpha) {
     Oracle o; memset(&o, 0, sizeof(o));

@@ -351,8 +351,9 @@ class Batch:
     """Host-side image of a batch of independent QPs for qpdo_amd_solve_batch (ctypes structs + the arrays they point
     to).  Building it is Python/scipy work; `run()` is the C call alone and may be repeated."""
 
-    def __init__(self, probs):
+    def __init__(self, probs, indices=None):
         self.keep, self.items, self.outs = [], (BatchItem * len(probs))(), []
+        self.indices = list(range(len(probs))) if indices is None else list(indices)   # global item numbers of this shard
         for i, p in enumerate(probs):
             A, Q = sp.csc_matrix(p["A"]), sp.csc_matrix(p["Q"])
             m, n = A.shape
@@ -382,6 +383,34 @@ class Batch:
             info["status"] = info["status"].decode()
             res.append(dict(info=info, x=x.copy(), y=y.copy()))
         return res, int(failed)
+
+
+def shard_indices(count, rank, world):
+    """Items of a batch of `count` independent QPs owned by `rank` of `world` processes (one per GPU): item b goes to
+    GPU b mod world.  Disjoint, complete and order-stable; no data-path collective."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("rank %r not in [0, %r)" % (rank, world))
+    return list(range(rank, count, world))
+
+
+def shard_batch(count, rank, world, make_problem):
+    """Batch of this rank's items only: make_problem(i) is called for the owned global indices."""
+    idx = shard_indices(count, rank, world)
+    return Batch([make_problem(i) for i in idx], indices=idx)
+
+
+def merge_shards(count, shards):
+    """shards: iterable of (indices, results) as returned per rank -> list of `count` results in global order."""
+    out = [None] * count
+    for idx, res in shards:
+        for i, r in zip(idx, res):
+            if out[i] is not None:
+                raise ValueError("item %d solved twice" % i)
+            out[i] = r
+    missing = [i for i, r in enumerate(out) if r is None]
+    if missing:
+        raise ValueError("items not solved: %r" % missing[:8])
+    return out
 
 
 def solve_batch(probs, settings=None, nthreads=16, **kw):

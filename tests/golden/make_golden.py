@@ -54,6 +54,9 @@ def main():
             prim_inf_cert=[float(v) for v in r["prim_inf_cert"]],
             dual_inf_cert=[float(v) for v in r["dual_inf_cert"]],
             kinds=[t["kind"] for t in tr], n_active=[t["n_active"] for t in tr],
+            # the whole per-pass trace (TraceRec of oracle/qpdo_oracle.c): one list per field
+            trace={f: [t[f] for t in tr] for f in ("kind", "n_active", "n_enter", "n_leave", "factor_branch", "tau",
+                                                    "res_prim", "res_dual", "res_prim_in", "res_dual_in", "sigma", "eps_in")},
         )
         o.close()
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_golden.json")

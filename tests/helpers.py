@@ -16,6 +16,12 @@ ITERATE_RTOL = 1e-9      # |x - x_ref|inf <= ITERATE_RTOL * max(1, |x_ref|inf)  
 ITERATE_RTOL_PCG = 1e-8  # same bound for the Jacobi-PCG solver: its stopping rule is a relative residual of 1e-12 on
                          # systems whose condition number reaches 1e12 late in a solve (weights 1/mu up to 1e9)
 KKT_ATOL = 1e-10         # |KKT residual - reference KKT residual| <= KKT_ATOL
+# per-pass trace (one record per loop pass of qpdo_solve, reference src/qpdo.c:343-449), HIP path vs oracle:
+TAU_RTOL = 1e-10         # linesearch step:  |tau - tau_ref| <= TAU_RTOL * max(1, |tau_ref|)          (dense LDL')
+TAU_RTOL_PCG = 1e-7      # same bound when the Newton system is solved by PCG to a 1e-12 relative residual
+NORM_RTOL = 1e-8         # the four residual norms of a pass: |v - v_ref| <= NORM_RTOL * max(|v_ref|, NORM_FLOOR)
+NORM_RTOL_PCG = 1e-6
+NORM_FLOOR = 1e-9        # norms below eps_abs/1000 are compared absolutely (they are differences of O(1) quantities)
 
 
 def load_golden():
@@ -39,3 +45,29 @@ def close_vec(a, b, rtol=ITERATE_RTOL):
         return bool(np.isnan(a).all())
     scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
     return bool(np.abs(a - b).max() <= rtol * scale) if b.size else True
+
+
+def assert_same_trace(got, ref, pcg=False, tau_rtol=None, norm_rtol=None):
+    """Per-pass comparison of the HIP path's trace with the oracle's (lists of dicts with the TraceRec fields of
+    oracle/qpdo_oracle.c:92-100 = QPDOAmdTraceRec of include/qpdo_amd_ext.h).  Integer fields (pass kind, active-set
+    size, rows entering / leaving, factor branch) must be IDENTICAL; sigma and eps_in are products of settings
+    constants and must be identical bit for bit; tau and the four residual norms within the stated tolerances."""
+    tau_rtol = tau_rtol if tau_rtol is not None else (TAU_RTOL_PCG if pcg else TAU_RTOL)
+    norm_rtol = norm_rtol if norm_rtol is not None else (NORM_RTOL_PCG if pcg else NORM_RTOL)
+    assert len(got) == len(ref), (len(got), len(ref))
+    for k, (g, r) in enumerate(zip(got, ref)):
+        for f in ("kind", "n_active", "n_enter", "n_leave", "factor_branch"):
+            assert int(g[f]) == int(r[f]), (k, f, g[f], r[f])
+        for f in ("sigma", "eps_in"):
+            assert float(g[f]) == float(r[f]), (k, f, g[f], r[f])
+        if int(r["kind"]) == 0:
+            assert abs(g["tau"] - r["tau"]) <= tau_rtol * max(1.0, abs(r["tau"])), (k, "tau", g["tau"], r["tau"])
+        for f in ("res_prim", "res_dual", "res_prim_in", "res_dual_in"):
+            assert abs(g[f] - r[f]) <= norm_rtol * max(abs(r[f]), NORM_FLOOR), (k, f, g[f], r[f])
+
+
+def trace_from_npz(z):
+    """list of per-pass dicts from a tests/golden/big_*.npz fixture"""
+    fields = [k[3:] for k in z.files if k.startswith("tr_")]
+    n = len(z["tr_kind"])
+    return [{f: z["tr_" + f][i] for f in fields} for i in range(n)]

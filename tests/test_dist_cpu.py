@@ -21,3 +21,39 @@ def test_two_rank_plumbing_gloo():
     assert r["world"] == 2 and r["tmax"] == 2.0
     assert r["tot"][0] == 30.0
     assert r["tot"][1] == 2 * r["seed0"] + 1          # rank 1 solves the next seed: a different instance
+
+
+def test_batch_shard_split_is_disjoint_complete_and_order_stable():
+    """pure host logic of the split: item b -> rank b mod world"""
+    from qpdo_amd import solver
+    for count in (0, 1, 7, 4096):
+        for world in (1, 2, 3, 8):
+            shards = [solver.shard_indices(count, r, world) for r in range(world)]
+            flat = sorted(i for s in shards for i in s)
+            assert flat == list(range(count))                       # complete, disjoint
+            assert all(s == sorted(s) for s in shards)              # order-stable
+            assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    import pytest
+    with pytest.raises(ValueError):
+        solver.shard_indices(4, 2, 2)
+    with pytest.raises(ValueError):
+        solver.merge_shards(3, [([0, 1], ["a", "b"])])               # item 2 missing
+    with pytest.raises(ValueError):
+        solver.merge_shards(2, [([0, 1], ["a", "b"]), ([1], ["c"])])  # item 1 twice
+    assert solver.merge_shards(3, [([1], ["b"]), ([0, 2], ["a", "c"])]) == ["a", "b", "c"]
+
+
+def test_two_rank_batch_shards_gloo():
+    """world-2 gloo: each rank builds only its own items of a C3 batch (no GPU, no solve): the shards are disjoint,
+    complete, in global order, and every rank generated exactly the instances it owns"""
+    env = dict(os.environ)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29579", os.path.join(ROOT, "tests", "_shard_worker.py"), "11"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["world"] == 2
+    a, b = r["ranks"]
+    assert a["indices"] == [0, 2, 4, 6, 8, 10] and b["indices"] == [1, 3, 5, 7, 9]
+    assert a["made"] == a["indices"] and b["made"] == b["indices"]
+    assert a["seeds"][0] != b["seeds"][0]

@@ -1,10 +1,14 @@
 """Parity of the HIP path (through the qpdo.h C-ABI) against the CPU oracle and the committed golden
 vectors.  Bar (BASELINE.json north_star): termination status, iteration count and outer-iteration count
 identical; iterates within ITERATE_RTOL; KKT residuals within KKT_ATOL."""
+import json
+import os
+
 import numpy as np
 import pytest
 
-from helpers import ITERATE_RTOL, ITERATE_RTOL_PCG, KKT_ATOL, close_vec, golden_problem, load_golden
+from helpers import (ITERATE_RTOL, ITERATE_RTOL_PCG, KKT_ATOL, assert_same_trace, close_vec, golden_problem,
+                     load_golden, trace_from_npz)
 from oracle import binding as ob
 from qpdo_amd import problems, solver
 
@@ -46,6 +50,8 @@ def test_against_golden_vectors(name, linsolve, gpu_required):
     assert_same_outcome(r, g, g["x"], g["y"], p, rtol_of(linsolve))
     assert [t["kind"] for t in r["trace"]] == g["kinds"]
     assert [t["n_active"] for t in r["trace"]] == g["n_active"]
+    gt = g["trace"]
+    assert_same_trace(r["trace"], [{f: gt[f][k] for f in gt} for k in range(len(gt["kind"]))], pcg=(linsolve == "pcg"))
     assert close_vec(r["prim_inf_cert"], g["prim_inf_cert"], 1e-6)
     assert close_vec(r["dual_inf_cert"], g["dual_inf_cert"], 1e-6)
 
@@ -76,10 +82,7 @@ def test_random_instances_match_live_oracle(seed, n, m, dens, neq, st, linsolve,
     ro = o.solve()
     r = solver.solve_problem(p, verbose=0, **st)
     assert_same_outcome(r, ro["info"], ro["x"], ro["y"], p, rtol_of(linsolve))
-    to, tg = o.trace(), r["trace"]
-    assert [t["kind"] for t in tg] == [t["kind"] for t in to]
-    assert [t["n_active"] for t in tg] == [t["n_active"] for t in to]
-    assert [t["factor_branch"] for t in tg] == [t["factor_branch"] for t in to]
+    assert_same_trace(r["trace"], o.trace(), pcg=(linsolve == "pcg"))
     o.close()
 
 
@@ -227,6 +230,15 @@ def test_dense_lowrank_update_matches_refactoring(gpu_required, monkeypatch):
     assert_same_outcome(r1, r0["info"], r0["x"], r0["y"], p)
     assert [t["n_active"] for t in r1["trace"]] == [t["n_active"] for t in r0["trace"]]
     assert [t["factor_branch"] for t in r1["trace"]] == [t["factor_branch"] for t in r0["trace"]]
+    # ... and from the oracle, which restates the reference's rank-update rules as the weight vector d
+    # (oracle/qpdo_oracle.c newton_direction / update_mu): the run that really took the low-rank path (checked above)
+    # must reproduce the oracle's outcome and its whole per-pass trace
+    o = ob.OracleSolver(p, ob.default_settings())
+    ro = o.solve()
+    assert_same_outcome(r1, ro["info"], ro["x"], ro["y"], p)
+    assert_same_trace(r1["trace"], o.trace())
+    assert any(t["factor_branch"] == 1 and t["n_enter"] + t["n_leave"] > 0 for t in r1["trace"])
+    o.close()
 
 
 def test_dense_chained_solve_matches_stepwise(gpu_required, monkeypatch):
@@ -282,16 +294,43 @@ def test_pcg_schur_fp32_inner_preconditioner_is_only_a_preconditioner(gpu_requir
     o.close()
 
 
-def test_config2_full_size_properties(gpu_required):
-    """BASELINE.json configs[1]: n=1e4, m=2e4, 1 % fill.  The oracle's dense factor is out of reach at this
-    size, so the check is through size-independent properties: termination status, independently recomputed
-    KKT residuals, complementarity, and agreement of the reported norms."""
-    p = problems.config_qp("C2")
-    r = solver.solve_problem(p, verbose=0)
-    assert r["info"]["status_val"] == 1
+BIG = sorted(f[4:-4] for f in os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+             if f.startswith("big_") and f.endswith(".npz"))
+
+
+@pytest.mark.parametrize("name", BIG)
+def test_production_size_matches_oracle_fixture(name, gpu_required, monkeypatch):
+    """Production sizes against committed oracle fixtures (tests/golden/big_<name>.npz, written by
+    tests/golden/make_golden_big.py with the oracle's direct LDL' = the reference's algorithm, src/qpdo.c:343-449,
+    src/newton.c:21-33).  The device runs its DEFAULT solver selection -- no QPDO_* override: dense MFMA LDL' with
+    look-ahead and low-rank updates at C2 (BASELINE.json configs[1], full size), PCG in Schur-complement mode over
+    the auto-selected LDS-staged slab kernels above QPDO_DENSE_MAX_N.  Bar: status, iterations, oterations and the
+    per-pass kind / n_active / n_enter / n_leave / factor branch IDENTICAL; tau and the four residual norms per pass
+    and the final iterates within the stated tolerances; plus the size-independent properties."""
+    for k in [k for k in os.environ if k.startswith("QPDO_") and k not in ("QPDO_DEVICE",)]:
+        monkeypatch.delenv(k)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_%s.npz" % name))
+    meta = json.loads(str(z["meta"]))
+    p = golden_problem(meta["spec"])
+    assert (p["n"], p["m"]) == (meta["n"], meta["m"])
+    r = solver.solve_problem(p, verbose=0, **meta["settings"])
+    dense = r["stats"]["linsolve"] == 1
+    assert dense == (p["n"] <= 12288)                       # the default selection, not an override
+    gi, oi = r["info"], meta["info"]
+    assert (gi["status_val"], gi["iterations"], gi["oterations"]) == (oi["status_val"], oi["iterations"], oi["oterations"])
+    assert_same_trace(r["trace"], trace_from_npz(z), pcg=not dense)
+    rt = ITERATE_RTOL if dense else ITERATE_RTOL_PCG
+    assert close_vec(r["x"], z["x"], rt), np.abs(r["x"] - z["x"]).max()
+    assert close_vec(r["y"], z["y"], rt), np.abs(r["y"] - z["y"]).max()
+    assert abs(gi["objective"] - oi["objective"]) <= 1e-9 * max(1.0, abs(oi["objective"]))
+    if dense:
+        assert r["stats"]["lowrank_solves"] > 0              # the kept-factor update path took part
+    else:
+        assert r["stats"]["schur_passes"] > 0
+    # size-independent properties: independently recomputed KKT residuals, agreement with the reported norms, complementarity
     rp, rd = problems.kkt_residuals(p, r["x"], r["y"])
     assert rp <= 1e-6 and rd <= 1e-6
-    assert abs(rp - r["info"]["res_prim_norm"]) <= 1e-9 and abs(rd - r["info"]["res_dual_norm"]) <= 1e-9
+    assert abs(rp - gi["res_prim_norm"]) <= 1e-9 and abs(rd - gi["res_dual_norm"]) <= 1e-9
     Ax = p["A"] @ r["x"]
     inside = (Ax > p["l"] + 1e-5) & (Ax < p["u"] - 1e-5)
     assert np.abs(r["y"][inside]).max() <= 1e-5
