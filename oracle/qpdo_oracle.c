@@ -144,6 +144,7 @@ typedef struct {
     int fix_status_reset;
 } Oracle;
 
+static int oracle_threads(void);
 static f64 now_s(void) {
     struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
     return (f64)t.tv_sec + 1e-9 * (f64)t.tv_nsec;
@@ -210,7 +211,7 @@ static void csc_mv(const Csc *M, const f64 *x, f64 *y) {
 }
 /* y = M' x, CSC general */
 static void csc_tmv(const Csc *M, const f64 *x, f64 *y) {
-#pragma omp parallel for schedule(static) if (M->p[M->ncol] > 200000)
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static) if (M->p[M->ncol] > 200000)
     for (i64 j = 0; j < M->ncol; j++) {
         f64 s = 0.0;
         for (i64 k = M->p[j]; k < M->p[j+1]; k++) s += M->x[k] * x[M->i[k]];
@@ -269,7 +270,7 @@ static void refresh_csr_A(Oracle *o) {
  * full row r is [columns j < r from the stored triangle] ++ [stored column r from the diagonal down]). */
 static void A_mv(const Oracle *o, const f64 *x, f64 *y) {
     if (!o->Arp || o->A.p[o->n] <= 200000) { csc_mv(&o->A, x, y); return; }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static)
     for (i64 r = 0; r < o->m; r++) {
         f64 s = 0.0;
         for (i64 a = o->Arp[r]; a < o->Arp[r+1]; a++) s += o->Arx[a] * x[o->Aci[a]];
@@ -308,7 +309,7 @@ static void build_csr_Q(Oracle *o) {
 }
 static void Q_mv(const Oracle *o, const f64 *x, f64 *y) {
     if (!o->Qrp) { csc_mv(&o->Q, x, y); return; }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static)
     for (i64 r = 0; r < o->n; r++) {
         f64 s = 0.0;
         for (i64 a = o->Qrp[r]; a < o->Qrp[r+1]; a++) s += o->Q.x[o->Qmap[a]] * x[o->Qci[a]];
@@ -593,6 +594,24 @@ static void compute_inner_residuals_norm(Oracle *o) {
 #define LDL_TR 10     /* micro row blocks per task: 240 rows */
 #define LDL_TC 16     /* micro column blocks per task: 128 columns */
 static int g_ldl_force_scalar = 0;
+/* threads used by the parallel regions of this file: min(cores, 16) unless ORACLE_THREADS or oracle_set_threads says
+ * otherwise (the fixtures and tests must not depend on it: every parallel form is bit-identical to its serial loop) */
+static int g_threads = 0;
+static int oracle_threads(void) {
+    if (g_threads <= 0) {
+        const char *e = getenv("ORACLE_THREADS");
+        int t = (e && *e) ? atoi(e) : 0;
+#ifdef _OPENMP
+        if (t <= 0) { t = omp_get_num_procs(); if (t > 16) t = 16; }
+#else
+        t = 1;
+#endif
+        g_threads = t < 1 ? 1 : t;
+    }
+    return g_threads;
+}
+void oracle_set_threads(int t) { g_threads = t; }
+int oracle_get_threads(void) { return oracle_threads(); }
 void oracle_set_ldl_scalar(int on) { g_ldl_force_scalar = on; }
 
 static void ldl_factor_scalar(f64 *K, i64 n) {
@@ -684,7 +703,7 @@ static void ldl_factor_blocked(f64 *K, i64 n) {
         if (p1 >= n) break;
         /* 2. rows below the panel: the same recurrence row by row (rows are independent) */
         i64 below = n - p1;
-#pragma omp parallel for schedule(dynamic, 1) if (below * nb > 20000)
+#pragma omp parallel for num_threads(oracle_threads()) schedule(dynamic, 1) if (below * nb > 20000)
         for (i64 c0 = 0; c0 < below; c0 += 128) {
             i64 r0 = p1 + c0, r1 = MINV(n, r0 + 128);
             for (i64 j = p0; j < p1; j++) {
@@ -700,7 +719,7 @@ static void ldl_factor_blocked(f64 *K, i64 n) {
         }
         /* 3. pack L (rows below, k-major per block of MR rows) and W = L * D (k-major per block of NR columns) */
         i64 nrb = (below + LDL_MR - 1) / LDL_MR, ncb = (below + LDL_NR - 1) / LDL_NR;
-#pragma omp parallel for schedule(static) if (below * nb > 20000)
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static) if (below * nb > 20000)
         for (i64 b = 0; b < nrb; b++) {
             f64 *dst = Apack + (size_t)b * LDL_MR * nb;
             i64 r0 = p1 + b*LDL_MR;
@@ -708,7 +727,7 @@ static void ldl_factor_blocked(f64 *K, i64 n) {
                 for (i64 r = 0; r < LDL_MR; r++)
                     dst[k*LDL_MR + r] = (r0 + r < n) ? K[(r0 + r) + (p0 + k)*n] : 0.0;
         }
-#pragma omp parallel for schedule(static) if (below * nb > 20000)
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static) if (below * nb > 20000)
         for (i64 b = 0; b < ncb; b++) {
             f64 *dst = Wpack + (size_t)b * LDL_NR * nb;
             i64 c0 = p1 + b*LDL_NR;
@@ -719,7 +738,7 @@ static void ldl_factor_blocked(f64 *K, i64 n) {
         /* 4. trailing update of the lower triangle: tasks of LDL_TR x LDL_TC micro-tiles (MR x NR each); inside a
          *    task the W tile of a column block stays in L1 while the packed rows stream from L2 */
         i64 ntr = (nrb + LDL_TR - 1) / LDL_TR, ntc = (ncb + LDL_TC - 1) / LDL_TC;
-#pragma omp parallel for collapse(2) schedule(dynamic, 1) if (below * below * nb > 200000)
+#pragma omp parallel for num_threads(oracle_threads()) collapse(2) schedule(dynamic, 1) if (below * below * nb > 200000)
         for (i64 tr = ntr - 1; tr >= 0; tr--)
             for (i64 tc = 0; tc < ntc; tc++) {
                 i64 rb0 = tr * LDL_TR, rb1 = MINV(nrb, rb0 + LDL_TR);
@@ -750,7 +769,7 @@ static void assemble_and_factor(Oracle *o) {
     f64 *K = o->K;
     /* every entry of K is built by one thread, contributions in the order of the serial loops (Q entry, then the
      * weighted rows of A in ascending row order, then sigma_f): column ranges per thread */
-#pragma omp parallel if (n >= 512)
+#pragma omp parallel num_threads(oracle_threads()) if (n >= 512)
     {
         i64 nt = 1, tid = 0;
 #ifdef _OPENMP
@@ -789,7 +808,7 @@ static void assemble_and_factor(Oracle *o) {
         }
         for (i64 j = jlo; j < jhi; j++) K[j + j*n] += o->sigma_f;
     }
-    if (g_ldl_force_scalar || n < 512) ldl_factor_scalar(K, n);
+    if (g_ldl_force_scalar || n < 1024) ldl_factor_scalar(K, n);
     else ldl_factor_blocked(K, n);
     o->factor_valid = 1; o->factor_dirty = 0;
 }
@@ -813,7 +832,7 @@ static void K_apply(Oracle *o, const f64 *v, f64 *out) {
     Q_mv(o, v, out);
     for (i64 i = 0; i < n; i++) out[i] += o->sigma_f * v[i];
     f64 *t = o->pc_t;
-#pragma omp parallel for schedule(static) if (o->A.p[n] > 200000)
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static) if (o->A.p[n] > 200000)
     for (i64 r = 0; r < m; r++) {
         f64 s = 0.0;
         if (o->d[r] != 0.0) {
@@ -822,7 +841,7 @@ static void K_apply(Oracle *o, const f64 *v, f64 *out) {
         }
         t[r] = s;
     }
-#pragma omp parallel for schedule(static) if (o->A.p[n] > 200000)
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static) if (o->A.p[n] > 200000)
     for (i64 j = 0; j < n; j++) {
         f64 s = 0.0;
         for (i64 k = o->A.p[j]; k < o->A.p[j+1]; k++) s += o->A.x[k] * t[o->A.i[k]];
@@ -839,7 +858,7 @@ static i64 pcg_solve(Oracle *o, const f64 *b, f64 *x) {
     for (i64 j = 0; j < n; j++) dg[j] = o->sigma_f;
     for (i64 j = 0; j < n; j++)
         for (i64 k = o->Q.p[j]; k < o->Q.p[j+1]; k++) if (o->Q.i[k] == j) dg[j] += o->Q.x[k];
-#pragma omp parallel for schedule(static) if (o->A.p[n] > 200000)
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static) if (o->A.p[n] > 200000)
     for (i64 j = 0; j < n; j++) {
         f64 s = 0.0;
         for (i64 k = o->A.p[j]; k < o->A.p[j+1]; k++) s += o->A.x[k] * o->A.x[k] * o->d[o->A.i[k]];

@@ -5,7 +5,7 @@ tolerance.  The instances are cheap for the oracle (n <= 160), so the sweep runs
 import numpy as np
 import pytest
 
-from helpers import close_vec
+from helpers import close_vec, same_trace_counts
 from oracle import binding as ob
 from qpdo_amd import problems, solver
 
@@ -61,10 +61,12 @@ def test_randomized_sweep_matches_oracle(mode, gpu_required, monkeypatch):
         o = ob.OracleSolver(p, ob.default_settings(**st))
         ro = o.solve()
         oi = dict(ro["info"]); ox, oy = np.array(ro["x"]), np.array(ro["y"])
+        to = o.trace()
         o.close()
         r = solver.solve_problem(p, verbose=0, **st)
         gi = r["info"]
         same = (gi["status_val"] == oi["status_val"] and gi["iterations"] == oi["iterations"] and gi["oterations"] == oi["oterations"])
+        same = same and same_trace_counts(r["trace"], to)      # per pass: kind, n_active, n_enter, n_leave, factor branch
         # a run stopped by max_iter is compared through its counts only (its iterate is mid-flight, not a solution)
         if same and oi["status_val"] not in (-3, -4, -5):
             same = close_vec(r["x"], ox, rtol) and close_vec(r["y"], oy, rtol)
@@ -114,9 +116,11 @@ def test_schur_mode_mid_size_instances_match_oracle(i, gpu_required, monkeypatch
     o = ob.OracleSolver(p, ob.default_settings(**st))
     ro = o.solve()
     oi, ox, oy = dict(ro["info"]), np.array(ro["x"]), np.array(ro["y"])
+    to = o.trace()
     o.close()
     r = solver.solve_problem(p, verbose=0, **st)
     gi = r["info"]
     assert (gi["status_val"], gi["iterations"], gi["oterations"]) == (oi["status_val"], oi["iterations"], oi["oterations"])
+    assert same_trace_counts(r["trace"], to)
     assert r["stats"]["schur_passes"] > 0
     assert close_vec(r["x"], ox, 1e-7) and close_vec(r["y"], oy, 1e-7)

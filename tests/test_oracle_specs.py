@@ -123,3 +123,35 @@ def test_warm_start_and_updates_sequence():
     p4 = dict(p3); p4["q"] = qn
     assert r4["info"]["status_val"] == 1 and max(problems.kkt_residuals(p4, r4["x"], r4["y"])) <= 1e-6
     o.close()
+
+
+@pytest.mark.parametrize("n", [1, 23, 25, 257, 600, 1100])
+def test_blocked_ldl_equals_scalar_ldl_bit_for_bit(n):
+    """the oracle's OpenMP/blocked dense LDL' (used for the production-size fixtures and the all-cores CPU baseline)
+    applies, per entry, the same subtractions in the same order as the plain left-looking loop: identical bits"""
+    import ctypes as C
+    L = ob.lib()
+    L.oracle_ldl_factor.argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_int]
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, max(3, n // 3)))
+    K0 = np.asfortranarray(B @ B.T + 0.1 * np.eye(n))
+    Ka, Kb = K0.copy(order="F"), K0.copy(order="F")
+    L.oracle_ldl_factor(Ka.ctypes.data_as(C.POINTER(C.c_double)), n, 1)
+    L.oracle_ldl_factor(Kb.ctypes.data_as(C.POINTER(C.c_double)), n, 0)
+    assert np.array_equal(np.tril(Ka), np.tril(Kb))
+    assert np.array_equal(np.triu(Ka, 1), np.triu(K0, 1))            # the upper triangle is never written
+    Lm = np.tril(Ka, -1) + np.eye(n)
+    assert np.abs(Lm @ np.diag(np.diag(Ka)) @ Lm.T - K0).max() <= 1e-10 * np.abs(K0).max()
+
+
+def test_parallel_row_gather_products_equal_the_column_scatter_bit_for_bit():
+    """inside a solve the oracle runs A x and Q x as row gathers on all cores (large matrices only); they must give
+    the bits of the column-ordered scatter that restates cholmod_sdmult (reference cholmod_interface.c:132-142)"""
+    p = problems.random_qp(77, 1600, 2400, 0.09)
+    assert p["A"].nnz > 200000 and p["Q"].nnz > 100000              # above the oracle's thresholds for the parallel forms
+    o = ob.OracleSolver(p, ob.default_settings(scaling=0, proximal=0))
+    x = np.random.default_rng(0).standard_normal(p["n"])
+    o.warm_start(x, None)                                          # Ax <- A x, Qx <- Q x (qpdo.c:247-254)
+    assert np.array_equal(o.vec("Ax"), ob.csc_mv(p["A"], x))
+    assert np.array_equal(o.vec("Qx"), ob.csc_mv(p["Q"], x, stype=-1))
+    o.close()
