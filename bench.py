@@ -1,28 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: Newton iterations/sec (+ time-to-eps) of the HIP path on a seeded
-random sparse QP, one process per GPU.
+"""bench.py -- headline benchmark: Newton iterations/sec (+ time-to-eps) of the HIP path on seeded random
+sparse QPs, one process per GPU.
 
-A "step" is one full cold-start qpdo_solve to eps_abs = 1e-6 (reference defaults, include/constants.h)
-on the workload; `value` = Newton passes (loop passes that ran update_iterate) of all timed solves of all
-ranks / wall time (max over ranks); `ms_per_step` = time-to-eps.  Inputs are resident in HBM before
-the timed region starts (qpdo_setup uploads, converts and scales them; that time is reported separately as
-setup_s).  N > 1: independent QPs (different seeds) per rank, no data-path collective ("weak").
+Workloads (--workload; BASELINE.json configs):
+  C4  one QP n=1e5, m=2e5, 1 % fill per GPU -- the configuration the metric is quoted on (default).  A "step" is one
+      full cold-start qpdo_solve to eps_abs = 1e-6 with the reference's default settings.
+  C2  one QP n=1e4, m=2e4, 1 % fill per GPU; same meaning of a step.
+  C3  a batch of 4096 MPC-sized QPs (n=120, m=360, 120 equality rows) sharded over the ranks (rank r solves items
+      r::N with ONE fused-kernel launch, no collective); a step is one pass over the whole batch.
+`value` = Newton passes (loop passes that ran update_iterate) of all timed steps of all ranks / wall time (max over
+ranks); `ms_per_step` = wall time per step (C4/C2: time-to-eps, inputs already in HBM; setup_s is reported beside it and
+`time_to_eps_incl_setup_s` adds it, which is what the reference's info->run_time measures, src/qpdo.c:461-464).
+N > 1: independent QPs (different seeds) per rank / disjoint shards of the batch: no data-path collective ("weak");
+--partition rows: ONE QP with the rows of A partitioned over the ranks and RCCL all-reduces ("strong").
 
 Adds to the JSON line:
-  roofline     -- HBM roofline of the dominant kernel (the Q CSR SpMV inside PCG): algorithmic bytes
-                  12 nnz + 4(rows+1) + 8 rows + 8 cols over the HIP-event duration sampled live in the timed solves.
-  cpu_baseline -- the CPU oracle (a port; the reference needs CHOLMOD, absent here) timed on this host.
+  roofline     -- HBM roofline of the dominant kernel: algorithmic bytes (12 nnz + 4(rows+1) + 8 rows + 8 cols) over the
+                  HIP-event duration sampled live in the timed solves on the solver's stream.
+  cpu_baseline -- the CPU oracle (a port: the reference needs CHOLMOD, absent here) MEASURED on this host, all cores of
+                  the process's CPU share, on a bounded sample of the same workload (no constants from profiles/).
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
+C3_COUNT = 4096           # BASELINE.json configs[2]
 
 
 def parse():
@@ -31,13 +40,15 @@ def parse():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--workload", default=os.environ.get("QPDO_BENCH_WORKLOAD", "C4"),
-                    help="C4 (n=1e5,m=2e5,1%%: the config the metric is quoted on), C2, C1 ...")
+                    help="C4 (n=1e5,m=2e5,1%%: the config the metric is quoted on), C2, C3 (sharded batch), C1 ...")
     ap.add_argument("--max-time", type=float, default=float(os.environ.get("QPDO_BENCH_MAX_TIME", "0")),
                     help="settings.max_time per solve in seconds (0 = reference default, unlimited)")
+    ap.add_argument("--max-iter", type=int, default=0, help="settings.max_iter (0 = reference default 10000)")
     ap.add_argument("--partition", default=os.environ.get("QPDO_BENCH_PARTITION", "independent"), choices=["independent", "rows"],
                     help="N > 1: 'independent' = one QP per GPU, no collective (weak scaling, default); 'rows' = ONE QP whose "
-                         "rows of A are partitioned over the GPUs with an RCCL all-reduce per A' product (strong scaling)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="bound of the cpu_baseline sample")
+                         "rows of A are partitioned over the GPUs with RCCL all-reduces (strong scaling)")
+    ap.add_argument("--batch-count", type=int, default=C3_COUNT, help="C3: number of QPs in the whole batch")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="bound of the cpu_baseline sample of the main workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the informational C2 / C3-batch measurements")
     ap.add_argument("--no-mixed-extra", action="store_true", help="skip the informational fp32-inner-preconditioner solve")
@@ -74,35 +85,152 @@ def allreduce(dist, vals, op="sum"):
     return t.tolist()
 
 
-def cpu_baseline(prob, seconds, cg_per_newton, cg_source):
-    """Bounded sample on this host's cores: `seconds` of the oracle's Jacobi-PCG on the same matrices
-    (scaling off: the CG iteration cost does not depend on the scaling values), single thread.  The oracle's
-    solver is plain Jacobi-PCG, so its rate is converted with the iterations per Newton pass that algorithm needs
-    (measured on the GPU with the same algorithm), not with the count of the GPU's Schur-complement mode."""
+# ---- CPU baselines: the oracle timed on this host's cores, bounded samples ----------------------------------------
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline_single(prob, seconds, mode):
+    """One QP, cold start, reference default settings, all cores (OpenMP in the oracle's products / factor).
+    mode 'direct': the reference's own algorithm (natural-order LDL' of Q + sigma I + A'DA, cholmod_interface.c:35-52);
+    mode 'pcg': Jacobi-PCG on the same operator, for sizes where the dense factor does not exist (C4: 80 GB).
+    The sample is the first `seconds` of the solve; value = Newton passes COMPLETED in it / the time at which the
+    last of them ended (early passes have the fewest active rows, so this flatters the CPU)."""
     from oracle import binding as ob
-    s = ob.default_settings(scaling=0, max_time=seconds)
-    o = ob.OracleSolver(prob, s, linsolve="pcg", pcg_tol=1e-12)
+    cores = host_cores()
+    ob.set_threads(cores)
+    t0 = time.time()
+    o = ob.OracleSolver(prob, ob.default_settings(), linsolve="dense" if mode == "direct" else "pcg", pcg_tol=1e-12)
+    t_setup = time.time() - t0
     o.set_deadline(seconds)
     t0 = time.time()
     o.solve()
     dt = time.time() - t0
-    info = o.info()
-    cg = info["lin_iters"]
+    tr, info = o.trace(), o.info()
     o.close()
-    cg_rate = cg / dt if dt > 0 else 0.0
-    newton_rate = cg_rate / cg_per_newton if cg_per_newton > 0 else None
-    return dict(value=newton_rate, unit="newton_iters/s", cores=1, kind="port",
-                sample=("%.1f s of the oracle's Jacobi-PCG on the same instance (scaling off, 1 thread): %d CG iterations "
-                        "= %.3f CG it/s, divided by the %.1f Jacobi-CG iterations per Newton pass (%s); the reference's "
-                        "own direct CHOLMOD path is not buildable here and would need ~80 GB / 3.3e14 flop per factor at C4"
-                        % (dt, cg, cg_rate, cg_per_newton, cg_source)),
-                cg_iters_per_s=cg_rate)
+    finished = info["status_val"] not in (-6,)
+    done = [t for t in tr if t["kind"] == 0 and (finished or mode == "direct" or t["t_end"] <= seconds)]
+    t_last = done[-1]["t_end"] if done else dt
+    cg = info["lin_iters"]
+    what = ("natural-order dense LDL' (the reference's direct algorithm), blocked + OpenMP" if mode == "direct"
+            else "Jacobi-PCG on the matrix-free Newton operator, OpenMP products (the reference's direct CHOLMOD path would need "
+                 "an ~80 GB / 3.3e14-flop factor at this size)")
+    return dict(value=(len(done) / t_last) if done else None, unit="newton_iters/s", cores=cores, kind="port",
+                sample=("first %.1f s of a cold-start solve of the same instance with the oracle (%s), default settings, %d threads: "
+                        "%d Newton passes completed by t=%.1f s%s; oracle setup %.1f s not included"
+                        % (dt, what, cores, len(done), t_last, ("" if mode == "direct" else ", %d CG iterations (%.2f it/s)" % (cg, cg / dt)), t_setup)),
+                newton_passes=len(done), seconds=t_last, solved_within_sample=bool(finished),
+                **({} if mode == "direct" else dict(cg_iters_per_s=cg / dt if dt > 0 else None)))
+
+
+def cpu_baseline_batch(probs, seconds, settings_over):
+    """A slice of the batch through the oracle, one QP per host thread at a time (ctypes releases the GIL), all cores.
+    Returns QPs/s and Newton passes/s over the QPs finished within `seconds`."""
+    from oracle import binding as ob
+    cores = host_cores()
+    ob.set_threads(1)
+    lock = threading.Lock()
+    state = dict(next=0, qps=0, newton=0)
+    t0 = time.time()
+
+    def work():
+        while True:
+            with lock:
+                i = state["next"]; state["next"] += 1
+            if i >= len(probs) or time.time() - t0 > seconds:
+                return
+            o = ob.OracleSolver(probs[i], ob.default_settings(**settings_over))
+            o.solve()
+            inf = o.info()
+            o.close()
+            with lock:
+                state["qps"] += 1; state["newton"] += inf["newton_passes"]
+    th = [threading.Thread(target=work) for _ in range(cores)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dt = time.time() - t0
+    return dict(value=state["newton"] / dt, unit="newton_iters/s", cores=cores, kind="port", qps_per_s=state["qps"] / dt,
+                sample="%d of the batch's QPs through the oracle (dense LDL' per QP, setup + solve), %d host threads, %.1f s" % (state["qps"], cores, dt))
+
+
+# ---- workloads -----------------------------------------------------------------------------------------------------
+def run_batch(a, rank, world, dist):
+    """C3: the batch sharded over the ranks (item b -> rank b mod world), one fused launch per rank and step."""
+    from qpdo_amd import problems, solver
+    count = a.batch_count
+    st = dict(verbose=0)
+    if a.max_iter > 0:
+        st["max_iter"] = a.max_iter
+    t0 = time.time()
+    B = solver.shard_batch(count, rank, world, lambda i: problems.config_qp("C3", i))
+    t_gen = time.time() - t0
+    for _ in range(max(1, a.warmup)):          # at least one: device arena + code objects
+        B.run(**st)
+    barrier(dist)
+    t0 = time.time()
+    newton = solved = failed = 0
+    for _ in range(a.steps):
+        res, f = B.run(**st)
+        failed += f
+        newton += sum(r["info"]["iterations"] - r["info"]["oterations"] for r in res)
+        solved += sum(r["info"]["status_val"] == 1 for r in res)
+    barrier(dist)
+    dt = time.time() - t0
+    dt_max = allreduce(dist, [dt], "max")[0]
+    tot_newton, tot_solved, tot_failed, tot_items = allreduce(dist, [newton, solved, failed, len(B.indices) * a.steps], "sum")
+    if rank != 0:
+        return None
+    cfg = problems.CONFIGS["C3"]
+    out = {
+        "metric": "primal-dual Newton iters/sec (+ time-to-eps) on random sparse QP", "value": tot_newton / dt_max, "unit": "newton_iters/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt_max / max(1, a.steps),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic (seeded counter-based generator, qpdo_amd/csrc/qpdo_gen.c)",
+        "config": {"workload": "C3: batch of %d MPC-sized QPs (n=%d, m=%d, %d equality rows, density %g) sharded over the GPUs "
+                               "(item b -> GPU b mod N), one fused-kernel launch per GPU and step, no collective; cold start, reference "
+                               "default settings%s" % (count, cfg["n"], cfg["m"], cfg["n_eq"], cfg["density"],
+                                                       (", max_iter=%d" % a.max_iter) if a.max_iter > 0 else " (max_iter=10000)"),
+                   "count": count, "n": cfg["n"], "m": cfg["m"], "parallelism": "independent QPs, batch sharded over ranks, no collective"},
+        "qps_per_s": tot_items / dt_max, "solved": tot_solved, "failed": tot_failed, "items": tot_items, "generate_s": t_gen,
+        "roofline": small_kernel_roofline(tot_newton / max(1, a.steps), dt_max / max(1, a.steps), world),
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        sl = [problems.config_qp("C3", i) for i in range(min(count, 512))]
+        out["cpu_baseline"] = cpu_baseline_batch(sl, a.cpu_seconds, {k: v for k, v in st.items() if k != "verbose"})
+    return out
+
+
+def small_kernel_roofline(newton_passes, seconds, n_gpus):
+    """k_small_solve keeps a QP's whole state in LDS: it is bound by LDS traffic and barrier latency, not by HBM.
+    Stated model (DESIGN.md section 3): per Newton pass the in-LDS LDL' reads/writes ~ (2/3) n^3 + m n^2 ... bytes of LDS;
+    reported here as achieved LDS GB/s against the 256-CU aggregate LDS peak."""
+    n, m = 120, 360
+    # per Newton pass, fp64 words moved through LDS (reads + writes), dominant terms:
+    #   assembly A'DA: m_active ~ m/2 rows x (nnz_row^2) ~ small; factor: n^3/3 MAC -> 2 reads + 1 write per MAC / reuse 1
+    lds_bytes = 8.0 * (n ** 3)            # ~3 LDS words per MAC x n^3/3 MACs (right-looking update streams the trailing block)
+    lds_bytes += 8.0 * 4 * n * n          # two triangular solves + K assembly read-modify-write
+    lds_bytes += 8.0 * 2 * m * 12 * 10    # bitonic sort of 2m keys: log^2 passes (~55) x 2m x 16 B, order of magnitude
+    peak = 256 * 128 * 2.4                # GB/s: 256 CUs x 128 B/clk x 2.4 GHz (MI355X_MICROARCH.md LDS section)
+    ach = newton_passes * lds_bytes / seconds / 1e9 / max(1, n_gpus)
+    return dict(bound="lds", kernel="k_small_solve (one workgroup per QP, whole state in LDS)", achieved=ach, peak=peak, unit="GB/s",
+                frac=ach / peak, traffic=None,
+                note="LDS-traffic model, not an HBM roofline: HBM traffic of this kernel is the problem data once (~70 KB per QP)")
 
 
 def main():
     a = parse()
     rank, world, dist = dist_setup(a.gpus)
     from qpdo_amd import problems, solver
+    if a.workload == "C3":
+        out = run_batch(a, rank, world, dist)
+        if rank == 0:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
     cfg = problems.CONFIGS[a.workload]
     t0 = time.time()
     rows_mode = (a.partition == "rows" and world > 1)
@@ -114,6 +242,8 @@ def main():
     st = dict(verbose=0)
     if a.max_time > 0:
         st["max_time"] = a.max_time
+    if a.max_iter > 0:
+        st["max_iter"] = a.max_iter
     t0 = time.time()
     s = solver.QPDO().setup(prob["Q"], prob["q"], prob["A"], prob["l"], prob["u"], Qstype=-1, **st)
     t_setup = time.time() - t0
@@ -152,13 +282,18 @@ def main():
     # of the PCG the bulk of the time is the inner solves' A_c product (k_spmv_slab<EpiSchurA>: the k active rows of A,
     # compact index space, k changes per pass, so bytes and time are summed over the samples); otherwise it is the Q
     # product of the PCG operator (k_spmv_slab<EpiPcgQ>).  A back-to-back micro-benchmark of the full-size kernel beside it.
-    pmc = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_spmv_c4.json")) as fh:
-            pmc = json.load(fh)
-    except Exception:
-        pass
-    if ac_n > at_n and ac_time > 0:
+    def load_profile(name):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                return json.load(fh)
+        except Exception:
+            return None
+    if s.stats()["linsolve"] == 1:
+        # dense LDL' (C2): the dominant kernel is the fp64-MFMA trailing update; MFMA utilisation comes from the committed
+        # PMC profile, the live figure here is the factor's flop rate from the solve's own statistics
+        roof = dict(bound="mfma", kernel="k_ldl_syrk (fp64 MFMA trailing update of the dense LDL')", achieved=None, peak=78.6, unit="TFLOP/s",
+                    frac=None, traffic=None, factor_count=s.stats()["factor_count"])
+    elif ac_n > at_n and ac_time > 0:
         bench_t, full_bytes = s.bench_spmv(0, reps=20)
         achieved = ac_bytes / ac_time / 1e9
         roof = dict(bound="hbm", kernel="k_spmv_slab<EpiSchurA> (S'p = p/d + A_c t: the active rows of A in the pass's compact index space)",
@@ -166,17 +301,15 @@ def main():
                     alg_bytes_per_launch=ac_bytes / ac_n, avg_launch_s=ac_time / ac_n, samples=int(ac_n),
                     microbench_GBs=full_bytes / bench_t / 1e9, spmv_A_GBs=None, spmv_At_GBs=None)
         if a.workload == "C4":
-            try:      # averaged over all real launches of this kernel in a profiled run of this same command
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_schur_inner_c4.json")) as fh:
-                    pin = json.load(fh)
-                roof["traffic"] = pin["k_spmv_slab<EpiSchurA> (A_c product)"]["traffic_bytes_avg"]
-                roof["traffic_source"] = ("profiles/r01_pmc_schur_inner_c4.json: 2*FETCH_SIZE + WRITE_SIZE averaged over the real launches of this kernel "
-                                          "in separate rocprofv3 --pmc passes over this command")
-            except Exception:
-                if pmc is not None:
-                    ratio = pmc["A  (CSR m x n)"]["traffic_over_alg"]
-                    roof["traffic"] = ratio * ac_bytes / ac_n
-                    roof["traffic_source"] = "profiles/r01_pmc_spmv_c4.json ratio for the same kernel on the full A, applied to the average compact launch"
+            # HBM bytes per launch from the PMC counters cannot be collected inside this process: the figure is the average over
+            # all real launches of this kernel in separate rocprofv3 --pmc passes over this same command (committed summary)
+            for name in ("r02_pmc_schur_inner_c4.json", "r01_pmc_schur_inner_c4.json"):
+                pin = load_profile(name)
+                if pin is not None:
+                    roof["traffic"] = pin["k_spmv_slab<EpiSchurA> (A_c product)"]["traffic_bytes_avg"]
+                    roof["traffic_source"] = ("profiles/%s: 2*FETCH_SIZE + WRITE_SIZE averaged over the real launches of this kernel in "
+                                              "separate rocprofv3 --pmc passes over this command" % name)
+                    break
         if at_n:
             q_t, q_b = s.bench_spmv(2, reps=5)
             roof["spmv_Q_live_GBs"] = q_b / (at_time / at_n) / 1e9
@@ -188,15 +321,16 @@ def main():
                     unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None, alg_bytes_per_launch=alg_bytes,
                     avg_launch_s=live_t, samples=int(at_n), microbench_GBs=alg_bytes / bench_t / 1e9,
                     spmv_A_GBs=None, spmv_At_GBs=None)
-        # HBM bytes per launch from the PMC counters cannot be collected inside this process; the figure comes from
-        # the committed rocprofv3 --pmc passes on the same workload and kernel (profiles/r01_pmc_spmv_c4.json), if present
+        pmc = load_profile("r01_pmc_spmv_c4.json")
         if pmc is not None and a.workload == "C4":
             roof["traffic"] = pmc["Q  (CSR n x n)"]["traffic_bytes"]
             roof["traffic_source"] = "profiles/r01_pmc_spmv_c4.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
-    for which, key in ((0, "spmv_A_GBs"), (1, "spmv_At_GBs")):
-        t_, b_ = s.bench_spmv(which, reps=20)
-        roof[key] = b_ / t_ / 1e9
+    if roof["bound"] == "hbm":
+        for which, key in ((0, "spmv_A_GBs"), (1, "spmv_At_GBs")):
+            t_, b_ = s.bench_spmv(which, reps=20)
+            roof[key] = b_ / t_ / 1e9
     out = None
+    all_solved = all(v == 1 for v in statuses)
     if rank == 0:
         out = {
             "metric": "primal-dual Newton iters/sec (+ time-to-eps) on random sparse QP",
@@ -213,27 +347,21 @@ def main():
                        "n": cfg["n"], "m": cfg["m"], "density": cfg["density"], "linsolve": ("pcg: Jacobi + heavy-row deflation, Schur-complement mode on %d of %d Newton passes" % (schur_passes, newton)) if s.stats()["linsolve"] == 0 else "dense-ldlt",
                        "parallelism": ("one QP, rows of A partitioned over the GPUs, RCCL all-reduce of A'y" if rows_mode
                                        else "independent QPs per GPU, no collective")},
-            "time_to_eps_s": dt_max / max(1, a.steps) if all(v == 1 for v in statuses) else None,
+            # time-to-eps: the solve alone (inputs resident in HBM), and with qpdo_setup added -- the reference's info->run_time
+            # covers setup + solve (src/qpdo.c:461-464)
+            "time_to_eps_s": dt_max / max(1, a.steps) if all_solved else None,
+            "time_to_eps_incl_setup_s": (dt_max / max(1, a.steps) + t_setup) if all_solved else None,
             "status_val": statuses, "iterations": iters, "oterations": oters, "newton_passes": tot_newton,
             "cg_iters": tot_cg, "kkt_prim": rp, "kkt_dual": rd,
             "setup_s": t_setup, "generate_s": t_gen,
             "roofline": roof,
         }
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cgpn, src = (cg / newton) if newton else 0.0, "this GPU run"
-        if schur_passes:      # the GPU count is not the CPU algorithm's: use the committed Jacobi-only GPU run of the same instance
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_c4_jacobi_reference.json")) as fh:
-                    jr = json.load(fh)
-                if jr.get("workload") == a.workload:
-                    cgpn, src = jr["cg_iters"] / jr["newton_passes"], "profiles/r01_c4_jacobi_reference.json: deflated Jacobi-PCG on the GPU, same instance"
-            except Exception:
-                pass
-        try:
-            out["cpu_baseline"] = cpu_baseline(prob, a.cpu_seconds, cgpn, src)
-        except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU line
-            out["cpu_baseline"] = dict(value=None, unit="newton_iters/s", cores=1, kind="port", sample="failed: %r" % (e,))
     s.delete()
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline_single(prob, a.cpu_seconds, "direct" if cfg["n"] <= 20000 else "pcg")
+        except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU line
+            out["cpu_baseline"] = dict(value=None, unit="newton_iters/s", cores=host_cores(), kind="port", sample="failed: %r" % (e,))
     if rank == 0 and world == 1 and schur_passes and not a.no_mixed_extra:
         # Informational extra, NOT part of `value`: the same solve with the opt-in fp32 copy of the inner preconditioner's
         # matrix values (QPDO_PCG_INNER_F32=1; every vector, accumulation and the outer CG on the exact K stay fp64).
@@ -254,25 +382,35 @@ def main():
             os.environ.pop("QPDO_PCG_INNER_F32", None)
     if rank == 0 and world == 1 and a.workload == "C4" and not a.no_other_configs:
         # Informational extras, NOT part of `value`: the other single-GPU configurations of BASELINE.json, measured in the
-        # same process (configs[1]: one QP n=1e4, m=2e4; configs[2]: 4096 MPC-sized QPs through the fused batch kernel).
+        # same process (configs[1]: one QP n=1e4, m=2e4; configs[2]: 4096 MPC-sized QPs through the fused batch kernel), each
+        # with its own measured CPU baseline
         try:
             p2 = problems.config_qp("C2")
             t0 = time.time(); s3 = solver.QPDO().setup(p2["Q"], p2["q"], p2["A"], p2["l"], p2["u"], Qstype=-1, verbose=0); ts = time.time() - t0
+            s3.solve()                                                            # warm-up (code objects, allocations)
             t0 = time.time(); r3 = s3.solve(); L.qpdo_amd_sync(s3._w); dt3 = time.time() - t0
             st3 = s3.stats(); s3.delete()
             out["other_configs"] = {"C2": dict(workload="n=10000, m=20000, density 0.01, cold start, default settings", time_to_eps_s=dt3, setup_s=ts,
                                                newton_iters_per_s=st3["newton_passes"] / dt3, status_val=r3["info"]["status_val"],
                                                iterations=r3["info"]["iterations"], linsolve="dense-ldlt" if st3["linsolve"] == 1 else "pcg",
                                                factor_count=st3["factor_count"], lowrank_solves=st3["lowrank_solves"])}
-            nb = 4096
+            if not a.no_cpu_baseline:
+                out["other_configs"]["C2"]["cpu_baseline"] = cpu_baseline_single(p2, 20.0, "direct")
+            nb = C3_COUNT
             probs = [problems.config_qp("C3", i) for i in range(nb)]
             B = solver.Batch(probs)
-            B.run(verbose=0, max_iter=300)                      # warm-up (device arena, code objects)
-            t0 = time.time(); resb, failed = B.run(verbose=0, max_iter=300); dtb = time.time() - t0
-            out["other_configs"]["C3_batch"] = dict(workload="%d QPs n=120, m=360 (120 equality rows), one fused-kernel launch, max_iter=300" % nb,
-                                                    seconds=dtb, qps_per_s=nb / dtb, failed=failed,
-                                                    newton_iters_per_s=sum(r_["info"]["iterations"] - r_["info"]["oterations"] for r_ in resb) / dtb,
-                                                    solved=sum(r_["info"]["status_val"] == 1 for r_ in resb))
+            c3 = {}
+            for label, kw in (("max_iter_default_10000", {}), ("max_iter_300", dict(max_iter=300))):
+                B.run(verbose=0, **kw)                      # warm-up (device arena, code objects)
+                t0 = time.time(); resb, failed = B.run(verbose=0, **kw); dtb = time.time() - t0
+                nwt = sum(r_["info"]["iterations"] - r_["info"]["oterations"] for r_ in resb)
+                c3[label] = dict(seconds=dtb, qps_per_s=nb / dtb, failed=failed, newton_iters_per_s=nwt / dtb,
+                                 solved=sum(r_["info"]["status_val"] == 1 for r_ in resb),
+                                 roofline=small_kernel_roofline(nwt, dtb, 1))
+            c3["workload"] = "%d QPs n=120, m=360 (120 equality rows), one fused-kernel launch, wall time through the Python class" % nb
+            if not a.no_cpu_baseline:
+                c3["cpu_baseline"] = cpu_baseline_batch(probs[:512], 10.0, {})
+            out["other_configs"]["C3_batch"] = c3
         except Exception as e:
             out.setdefault("other_configs", {})["error"] = repr(e)
     if rank == 0:

@@ -62,6 +62,10 @@ typedef struct {
     long   lowrank_cols;    /* rows that entered the low-rank set (one multi-RHS solve column each)                 */
     long   lowrank_sweeps;  /* refinement sweeps of the low-rank solves (one kept-factor solve + 3 SpMV each)        */
     long   lowrank_rejects; /* low-rank solves abandoned for a refactorization (ill-conditioned downdate)          */
+    long   pcg_soft_accepts;/* PCG solves that stopped at the iteration cap or stagnated and were accepted because their relative
+                             * residual was <= 1e-8; a worse or NaN residual ends qpdo_solve with status QPDO_ERROR instead      */
+    long   chain_fallbacks; /* dense triangular solves redone with the stepwise kernels (dense LDL')                  */
+    double pcg_max_relres;  /* largest ||r||/||rhs|| a PCG solve of the last qpdo_solve ended with (tolerance QPDO_PCG_TOL)      */
 } QPDOAmdStats;
 
 int  qpdo_amd_device_count(void);
@@ -97,9 +101,13 @@ int  qpdo_amd_dist_config(int rank, int world, const void *rccl_unique_id, qpdo_
 int  qpdo_amd_dist_unique_id(void *out128);
 
 /* ---- batch of independent QPs (BASELINE.json configs[2]: MPC-sized problems, no collective) --------------
- * Every item is set up, (optionally warm started,) solved and cleaned up through the same entry points as above,
- * by `nthreads` host threads, each with its own workspace and HIP stream on the device of this process
- * (QPDO_DEVICE); across GPUs the caller shards the item list over processes.  x (n) and y (m) receive the
+ * Default path (every item has n, m <= 1024 and passes the checks of qpdo_setup): ONE launch of the fused kernel
+ * k_small_solve, one workgroup per item running the item's qpdo_setup (Ruiz scaling), qpdo_warm_start and the whole
+ * qpdo_solve loop, including settings->max_time (QPDO_MAX_TIME_REACHED, checked at the end of every pass as in the
+ * reference, src/qpdo.c:441-447) and the three PROFILING times of QPDOInfo (per item, from the device wall clock).
+ * Otherwise, or with QPDO_BATCH=threads: every item goes through the entry points above on `nthreads` host threads, each
+ * with its own workspace and HIP stream on the device of this process (QPDO_DEVICE).  Across GPUs the caller shards
+ * the item list over processes (item b -> GPU b mod G; qpdo_amd/solver.py shard_indices).  x (n) and y (m) receive the
  * solution (NaN for infeasible statuses, as the reference's mex gateway does), info the final QPDOInfo. */
 typedef struct {
     const QPDOData *data;       /* problem (caller-owned, read only)                     */

@@ -33,7 +33,7 @@ class TraceRec(C.Structure):
                 ("n_leave", C.c_int64), ("factor_branch", C.c_int64), ("lin_iters", C.c_int64),
                 ("tau", C.c_double), ("res_prim", C.c_double), ("res_dual", C.c_double),
                 ("res_prim_in", C.c_double), ("res_dual_in", C.c_double),
-                ("sigma", C.c_double), ("eps_in", C.c_double)]
+                ("sigma", C.c_double), ("eps_in", C.c_double), ("t_end", C.c_double)]
 
 
 def build(force=False):
@@ -57,6 +57,8 @@ def lib():
         L.oracle_set_linsolve.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int64]
         L.oracle_set_fix_status_reset.argtypes = [C.c_void_p, C.c_int]
         L.oracle_set_deadline.argtypes = [C.c_void_p, C.c_double]
+        L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_get_threads.restype = C.c_int
         L.oracle_warm_start.argtypes = [C.c_void_p, dp, dp]
         L.oracle_solve.argtypes = [C.c_void_p]
         L.oracle_update_bounds.argtypes = [C.c_void_p, dp, dp]
@@ -233,3 +235,12 @@ def pwa_linesearch(eta, beta, delta, alpha):
     delta = np.ascontiguousarray(delta, np.float64)
     alpha = np.ascontiguousarray(alpha, np.float64)
     return float(lib().oracle_pwa_linesearch(len(delta) // 2, float(eta), float(beta), _dp(delta), _dp(alpha)))
+
+
+def set_threads(n):
+    """threads of the oracle's OpenMP regions (default min(cores, 16); results do not depend on it)"""
+    lib().oracle_set_threads(int(n))
+
+
+def get_threads():
+    return int(lib().oracle_get_threads())

@@ -100,6 +100,7 @@ typedef struct {
     f64 tau;
     f64 res_prim, res_dual, res_prim_in, res_dual_in;
     f64 sigma, eps_in;
+    f64 t_end;          /* seconds from the start of oracle_solve to the end of this pass (cpu_baseline sampling) */
 } TraceRec;
 
 typedef struct {
@@ -261,6 +262,7 @@ static void build_csr_A(Oracle *o) {
 }
 static void refresh_csr_A(Oracle *o) {
     i64 nnz = o->A.p[o->n];
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static) if (nnz > 200000)
     for (i64 s = 0; s < nnz; s++) o->Arx[s] = o->A.x[o->Amap[s]];
 }
 
@@ -323,24 +325,44 @@ static void limit_scaling(f64 *D, i64 n) { /* scaling.c:13-18 */
 }
 static void scale_data(Oracle *o, i64 iters) {
     i64 n = o->n, m = o->m;
+    const i64 nnzA = o->A.p[n];
+    const int par = nnzA > 200000;       /* max, sqrt, products: elementwise or order-independent => same bits on any thread count */
     f64 *Dt = dvec(n), *Et = dvec(m);
     for (i64 i = 0; i < n; i++) o->D[i] = 1.0;
     for (i64 i = 0; i < m; i++) o->E[i] = 1.0;
     for (i64 it = 0; it < iters; it++) {
-        csc_inf_norm_cols(&o->A, Dt);
-        csc_inf_norm_rows(&o->A, Et);
+        if (par && o->Arp) {
+            /* mat_inf_norm_cols / mat_inf_norm_rows (cholmod_interface.c:162-199) over the column / row access copies */
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static)
+            for (i64 j = 0; j < n; j++) {
+                f64 e = 0.0;
+                for (i64 k = o->A.p[j]; k < o->A.p[j+1]; k++) e = MAXV(ABSV(o->A.x[k]), e);
+                Dt[j] = e;
+            }
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static)
+            for (i64 i = 0; i < m; i++) {
+                f64 e = 0.0;
+                for (i64 a = o->Arp[i]; a < o->Arp[i+1]; a++) e = MAXV(ABSV(o->A.x[o->Amap[a]]), e);
+                Et[i] = e;
+            }
+        } else {
+            csc_inf_norm_cols(&o->A, Dt);
+            csc_inf_norm_rows(&o->A, Et);
+        }
         limit_scaling(Dt, n); limit_scaling(Et, m);
         for (i64 i = 0; i < n; i++) Dt[i] = 1.0 / sqrt(Dt[i]);
         for (i64 i = 0; i < m; i++) Et[i] = 1.0 / sqrt(Et[i]);
-        /* cholmod_scale ROW then COL (scaling.c:56-57) */
-        for (i64 j = 0; j < n; j++)
+        /* cholmod_scale ROW then COL (scaling.c:56-57): two separately rounded multiplications per entry */
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static) if (par)
+        for (i64 j = 0; j < n; j++) {
             for (i64 k = o->A.p[j]; k < o->A.p[j+1]; k++) o->A.x[k] *= Et[o->A.i[k]];
-        for (i64 j = 0; j < n; j++)
             for (i64 k = o->A.p[j]; k < o->A.p[j+1]; k++) o->A.x[k] *= Dt[j];
+        }
         vec_ew_prod(o->D, Dt, o->D, n);
         vec_ew_prod(o->E, Et, o->E, m);
     }
     /* Q <- D Q D (cholmod_scale SYM), q <- D q  (scaling.c:66-69) */
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static) if (par)
     for (i64 j = 0; j < n; j++) {
         f64 t = o->D[j];
         for (i64 k = o->Q.p[j]; k < o->Q.p[j+1]; k++) o->Q.x[k] *= t * o->D[o->Q.i[k]];
@@ -421,6 +443,7 @@ Oracle *oracle_setup(i64 n, i64 m,
     o->sol_x = dvec(n); o->sol_y = dvec(m);
     o->reset_newton = 1;
     o->pcg_tol = 1e-12; o->pcg_maxit = 20000;
+    build_csr_A(o);                     /* pattern + slot map; values are refreshed after the scaling */
     if (s->scaling) {
         o->scaled = 1;
         o->D = dvec(n); o->Dinv = dvec(n); o->E = dvec(m); o->Einv = dvec(m);
@@ -430,7 +453,7 @@ Oracle *oracle_setup(i64 n, i64 m,
     } else {
         o->norm_q = vec_norm_inf(o->q, n);
     }
-    build_csr_A(o); refresh_csr_A(o); build_csr_Q(o);
+    refresh_csr_A(o); build_csr_Q(o);
     o->status_val = ST_UNSOLVED;
     o->setup_time = now_s() - t0;
     return o;
@@ -1221,7 +1244,9 @@ void oracle_solve(Oracle *o) {
             o->newton_passes++;
         }
         o->run_time = o->setup_time + (now_s() - t0);
+        tr = &o->trace[o->ntrace - 1]; tr->t_end = now_s() - t0;
         if (o->run_time > o->s.max_time) { o->status_val = ST_MAX_TIME; break; }
+        if (o->deadline > 0 && now_s() > o->deadline) { o->status_val = ST_MAX_TIME; break; }   /* cpu_baseline sampling */
     }
     if (o->status_val == ST_UNSOLVED) o->status_val = ST_MAX_ITER;
     o->iterations = iter; o->oterations = oter;

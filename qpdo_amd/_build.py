@@ -95,3 +95,35 @@ def ensure_lib():
 
 def build_all(force=False, verbose=False):
     return build_gen(force), build_lib(force, verbose)
+
+
+def build_abi_driver(out_dir, sanitize=False):
+    """Compiles tests/abi_driver.c -- a plain-C caller that includes only include/qpdo.h -- and links it against the
+    product library.  sanitize=True: the host driver (qpdo_api.c, gcc) is rebuilt with -fsanitize=address,undefined and
+    linked with the already compiled device objects into libqpdo_amd_asan.so inside out_dir (the product library in
+    the tree is not touched); the driver is instrumented too.  Returns the path of the executable."""
+    root = os.path.dirname(_HERE)
+    src = os.path.join(root, "tests", "abi_driver.c")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "abi_driver_asan" if sanitize else "abi_driver")
+    if not sanitize:
+        lib = ensure_lib()
+        subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Werror", "-I", INCLUDE, src, "-o", exe,
+                               "-L", os.path.dirname(lib), "-l:" + os.path.basename(lib), "-Wl,-rpath," + os.path.dirname(lib), "-lm"])
+        return exe
+    cc = hipcc()
+    if cc is None:
+        raise RuntimeError("hipcc not found")
+    objs = [os.path.join(CSRC, s + ".o") for s in HIP_SOURCES]
+    if not all(os.path.exists(o) for o in objs):
+        build_lib(force=True)
+    api = os.path.join(out_dir, "qpdo_api_asan.o")
+    san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"]
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", *san, "-ffp-contract=off", "-fopenmp", "-fPIC", "-Wall", "-I", INCLUDE, "-I", CSRC,
+                           "-c", os.path.join(CSRC, "qpdo_api.c"), "-o", api])
+    so = os.path.join(out_dir, "libqpdo_amd_asan.so")
+    rt = [subprocess.check_output(["gcc", "-print-file-name=" + n], text=True).strip() for n in ("libgomp.so", "libasan.so", "libubsan.so")]
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, api, *objs, "-lm", "-lpthread", "-L/opt/rocm/lib", "-lrccl", *rt])
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", *san, "-Wall", "-I", INCLUDE, src, "-o", exe, "-L", out_dir, "-lqpdo_amd_asan",
+                           "-Wl,-rpath," + out_dir, "-lm"])
+    return exe

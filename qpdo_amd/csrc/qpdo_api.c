@@ -299,15 +299,35 @@ static c_float *vec_dup(const c_float *a, size_t n) {
     return b;
 }
 
-/* distributed configuration for the workspaces created next in this process */
+/* Distributed configuration for the workspaces created next in this process (read once, under the lock, by each
+ * qpdo_setup).  An RCCL unique id creates exactly ONE communicator: the qpdo_setup that consumes it clears it, and a
+ * further distributed setup without a fresh qpdo_amd_dist_config fails with a message instead of hanging in
+ * ncclCommInitRank on a spent id.  The host-callback mode has no such limit. */
 static QdevDist g_dist = {0, 1, 0, 0, 0, 0, NULL, NULL, {0}};
+static int g_dist_has_id = 0, g_dist_id_spent = 0;
+static pthread_mutex_t g_dist_mu = PTHREAD_MUTEX_INITIALIZER;
 int qpdo_amd_dist_config(int rank, int world, const void *rccl_unique_id, qpdo_amd_allreduce_fn fn, void *ctx) {
     if (world < 1 || rank < 0 || rank >= world) return -1;
+    if (world > 1 && !fn && !rccl_unique_id) return -1;
+    pthread_mutex_lock(&g_dist_mu);
     memset(&g_dist, 0, sizeof(g_dist));
     g_dist.rank = rank; g_dist.world = world; g_dist.fn = (qdev_allreduce_fn)fn; g_dist.ctx = ctx;
-    if (rccl_unique_id) memcpy(g_dist.nccl_id, rccl_unique_id, 128);
-    if (world > 1 && !fn && !rccl_unique_id) return -1;
+    g_dist_has_id = 0; g_dist_id_spent = 0;
+    if (rccl_unique_id && !fn) { memcpy(g_dist.nccl_id, rccl_unique_id, 128); g_dist_has_id = 1; }
+    pthread_mutex_unlock(&g_dist_mu);
     return 0;
+}
+/* snapshot for one qpdo_setup; returns 0, or -1 when the RCCL id of the configuration has already been used */
+static int dist_take(QdevDist *out) {
+    int rc = 0;
+    pthread_mutex_lock(&g_dist_mu);
+    *out = g_dist;
+    if (g_dist.world > 1 && !g_dist.fn) {
+        if (!g_dist_has_id || g_dist_id_spent) rc = -1;
+        else g_dist_id_spent = 1;
+    }
+    pthread_mutex_unlock(&g_dist_mu);
+    return rc;
 }
 int qpdo_amd_dist_unique_id(void *out128) { return qdev_rccl_unique_id(out128); }
 
@@ -399,11 +419,16 @@ QPDOWorkspace *qpdo_setup(const QPDOData *data, const QPDOSettings *settings) {
         }
         device = device % ndev;
         int rc;
-        if (g_dist.world <= 1) {
+        QdevDist dd;
+        if (dist_take(&dd)) {
+            host_csr_free(&Ar); host_csr_free(&At); host_csr_free(&Qf);
+            QPDO_EPRINT("the RCCL unique id of qpdo_amd_dist_config has already created a communicator: call qpdo_amd_dist_config "
+                        "with a fresh id before setting up another row-partitioned workspace"); goto fail;
+        }
+        if (dd.world <= 1) {
             rc = qdev_create(&work->chol->dev, device, (int32_t)n, (int32_t)m, &a, &t, &qf, work->data->q, work->data->l, work->data->u);
         } else {
             /* row partition: rows [m0, m0+mloc) of A, the same columns of A', rows [n0, n0+nloc) of Q */
-            QdevDist dd = g_dist;
             const int64_t rpm = ((int64_t)m + dd.world - 1) / dd.world, rpn = ((int64_t)n + dd.world - 1) / dd.world;
             int64_t m0 = (int64_t)dd.rank * rpm; if (m0 > (int64_t)m) m0 = (int64_t)m;
             int64_t m1 = m0 + rpm; if (m1 > (int64_t)m) m1 = (int64_t)m;
@@ -800,6 +825,9 @@ int qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out) {
     out->lowrank_cols = (long)st.lowrank_cols;
     out->lowrank_sweeps = (long)st.lowrank_sweeps;
     out->lowrank_rejects = (long)st.lowrank_rejects;
+    out->pcg_soft_accepts = (long)st.pcg_soft_accepts;
+    out->chain_fallbacks = (long)st.chain_fallbacks;
+    out->pcg_max_relres = st.pcg_max_relres;
     return 0;
 }
 

@@ -46,6 +46,9 @@ typedef struct {
     int64_t lowrank_cols;       /* rows that received a low-rank slot (multi-RHS solve columns)   */
     int64_t lowrank_sweeps;     /* refinement sweeps of those solves (each one kept-factor solve + 3 SpMV) */
     int64_t lowrank_rejects;    /* low-rank solves abandoned for a refactorization (tiny pivot)   */
+    int64_t pcg_soft_accepts;   /* PCG solves that hit the iteration cap / stagnated but were accepted (rel. residual <= 1e-8) */
+    int64_t chain_fallbacks;    /* dense solves redone stepwise after a polled triangular solve lost a producer */
+    double  pcg_max_relres;     /* largest relative residual ||r|| / ||rhs|| any PCG solve of the last qpdo_solve ended with   */
 } QdevStats;
 
 int qdev_device_count(void);

@@ -345,6 +345,7 @@ __device__ void small_status(QPDOInfo &info, long st) {
         case QPDO_PRIMAL_INFEASIBLE: s = "primal infeasible"; break;
         case QPDO_DUAL_INFEASIBLE: s = "dual infeasible"; break;
         case QPDO_MAX_ITER_REACHED: s = "maximum iterations reached"; break;
+        case QPDO_MAX_TIME_REACHED: s = "max time exceeded"; break;
         case QPDO_NON_CVX: s = "unrecognised status value"; break;
         case QPDO_UNSOLVED: s = "unsolved"; break;
         case QPDO_ERROR: s = "error"; break;
@@ -366,6 +367,11 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
     if ((int)blockIdx.x >= count) return;
     SmallQP &P = probs[blockIdx.x];
     const int n = P.n, m = P.m;
+    // info->setup_time / solve_time / run_time of this item (reference PROFILING build, qpdo.c:79-82,327-329,461-464) and the
+    // max_time limit (qpdo.c:441-447): the 100 MHz wall clock, read by one lane and broadcast so that every decision taken from
+    // it is uniform over the workgroup.  Time never enters the arithmetic.
+    const long long t_begin = wall_clock64();
+    const bool timed = st.max_time < 1e19;
     double *NVp[NV_COUNT]; double *V[MV_COUNT];
     for (int i = 0; i < NV_COUNT; i++) NVp[i] = P.nv + (size_t)i * n;
     for (int i = 0; i < MV_COUNT; i++) V[i] = P.mv + (size_t)i * m;
@@ -433,6 +439,7 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
     long iter = 0, oter = 0, iter_old = 0, status = QPDO_UNSOLVED, newton = 0, nfactor = 0;
     double rpn = 0, rdn = 0, rpin = 0, rdin = 0;
     long long tph = P.prof ? wall_clock64() : 0;
+    const long long t_solve = wall_clock64();
     for (iter = 0; iter < st.max_iter; iter++) {
         // outer + inner residuals (iteration.c:30-93)
         FOR_T(i, m) {
@@ -623,6 +630,12 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
             newton++;
             PH(PH_UPDATE);
         }
+        if (timed) {                                  // qpdo.c:441-447: checked at the end of every pass, iter is not advanced
+            SYNC;
+            if (threadIdx.x == 0) sm[18] = (double)(wall_clock64() - t_begin) * 1e-8;
+            SYNC;
+            if (sm[18] > st.max_time) { status = QPDO_MAX_TIME_REACHED; break; }
+        }
     }
     if (status == QPDO_UNSOLVED) status = QPDO_MAX_ITER_REACHED;
     // store_solution (termination.c:82-92) + objective (iteration.c:185-221)
@@ -649,6 +662,10 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
         P.info.iterations = iter; P.info.oterations = oter;
         P.info.res_prim_norm = rpn; P.info.res_dual_norm = rdn; P.info.res_prim_in_norm = rpin; P.info.res_dual_in_norm = rdin;
         P.info.objective = obj;
+        const long long t_end = wall_clock64();
+        P.info.setup_time = (double)(t_solve - t_begin) * 1e-8;          // scaling + warm start + initialize_mu of this item
+        P.info.solve_time = (double)(t_end - t_solve) * 1e-8;
+        P.info.run_time = P.info.setup_time + P.info.solve_time;
         small_status(P.info, status);
         P.newton_passes = newton; P.factor_count = nfactor;
     }
@@ -737,8 +754,18 @@ int qdev_small_eligible(long count, const void *items_) {
         const QPDOData *d = items[i].data;
         if (!d || !d->Q || !d->A) return 0;
         if (d->n < 1 || d->n > SM_MAX_N || d->m > SM_MAX_M) return 0;
-        if ((d->Q->itype != 0 && d->Q->itype != 2) || (d->A->itype != 0 && d->A->itype != 2)) return 0;
-        if (d->Q->xtype != 1 || d->A->xtype != 1 || d->Q->dtype != 0 || d->A->dtype != 0) return 0;
+        // the checks qpdo_setup makes before it touches a matrix (qpdo_api.c sparse_ok + dimensions): anything else goes to
+        // the generic path, which rejects it with a message instead of indexing out of bounds here
+        const cholmod_sparse *Ms[2] = {d->Q, d->A};
+        for (int k = 0; k < 2; k++) {
+            const cholmod_sparse *M = Ms[k];
+            if (!M->p || (M->itype != 0 && M->itype != 2) || M->xtype != 1 || M->dtype != 0) return 0;
+            if (!M->packed && M->nz) return 0;
+            const long long nnz = idx_at(M->p, M->itype, (long long)M->ncol);
+            if (nnz < 0 || nnz >= 2147483647LL || (nnz > 0 && (!M->i || !M->x))) return 0;
+        }
+        if (d->Q->nrow != d->n || d->Q->ncol != d->n || d->A->nrow != d->m || d->A->ncol != d->n) return 0;
+        if (!d->q || (d->m > 0 && (!d->l || !d->u))) return 0;
     }
     return 1;
 }

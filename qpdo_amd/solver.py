@@ -91,7 +91,8 @@ class Stats(C.Structure):
                 ("spmv_Q_avg_s", C.c_double), ("spmv_Q_samples", C.c_long),
                 ("spmv_Ac_time_s", C.c_double), ("spmv_Ac_bytes", C.c_double), ("spmv_Ac_samples", C.c_long),
                 ("schur_passes", C.c_long), ("lowrank_solves", C.c_long), ("lowrank_cols", C.c_long), ("lowrank_sweeps", C.c_long),
-                ("lowrank_rejects", C.c_long)]
+                ("lowrank_rejects", C.c_long), ("pcg_soft_accepts", C.c_long), ("chain_fallbacks", C.c_long),
+                ("pcg_max_relres", C.c_double)]
 
 
 API_SYMBOLS = ["qpdo_set_default_settings", "qpdo_setup", "qpdo_warm_start", "qpdo_solve", "qpdo_update_settings",

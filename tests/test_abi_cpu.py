@@ -86,3 +86,30 @@ def test_problem_io_round_trip(tmp_path):
     assert (q["A"] != p["A"]).nnz == 0 and (q["Q"] != p["Q"]).nnz == 0
     assert np.array_equal(q["q"], p["q"]) and np.array_equal(q["l"], p["l"]) and q["Qstype"] == -1
     assert st["max_iter"] == 123 and st["eps_abs"] == 1e-6 and res["info"]["iterations"] == 5
+
+
+def test_header_compiles_from_c_and_layout_asserts_hold(tmp_path):
+    """tests/abi_driver.c includes only include/qpdo.h; its _Static_asserts pin every struct member offset of the
+    reference's DLONG + PROFILING layout (include/types.h); -Wall -Werror"""
+    import subprocess
+    exe = _build.build_abi_driver(str(tmp_path))
+    assert os.path.exists(exe)
+    if not has_gpu():      # with a GPU the full run is tests/test_gpu_abi.py
+        out = subprocess.run([exe, "--no-device"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "qpdo_setup returned NULL" in out.stdout
+
+
+def test_host_driver_under_address_and_ub_sanitizers(tmp_path):
+    """the host path (qpdo_api.c: validation, the threaded CSC -> CSR conversions with both index widths
+    and all three storages of Q, clean-up after a failed setup) under AddressSanitizer + UBSan + LeakSanitizer, driven by
+    the compiled-C caller up to the point where the library finds no HIP device.  (GPU sanitizers do not exist on this
+    pool; device code is covered by the parity tests.)"""
+    import subprocess
+    exe = _build.build_abi_driver(str(tmp_path), sanitize=True)
+    env = dict(os.environ, QPDO_SETUP_THREADS="5", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    out = subprocess.run([exe, "--no-device"], capture_output=True, text=True, timeout=300, env=env)
+    txt = out.stdout + out.stderr
+    assert out.returncode == 0, txt[-3000:]
+    assert "AddressSanitizer" not in txt and "runtime error" not in txt and "LeakSanitizer" not in txt, txt[-3000:]
+    assert txt.count("random instance") == 4

@@ -155,3 +155,25 @@ def test_parallel_row_gather_products_equal_the_column_scatter_bit_for_bit():
     assert np.array_equal(o.vec("Ax"), ob.csc_mv(p["A"], x))
     assert np.array_equal(o.vec("Qx"), ob.csc_mv(p["Q"], x, stype=-1))
     o.close()
+
+
+def test_parallel_ruiz_scaling_equals_numpy_restatement_bit_for_bit():
+    """scale_data on all cores (matrices above 2e5 nonzeros): maxima, square roots and the two per-entry multiplications
+    are elementwise / order-independent, so D and E must equal a numpy restatement of reference scaling.c:31-64 exactly"""
+    p = problems.random_qp(78, 1500, 2600, 0.09)
+    assert p["A"].nnz > 200000
+    o = ob.OracleSolver(p, ob.default_settings(scaling=10))
+    A = p["A"].tocsc().copy(); A.sort_indices()
+    cols = np.repeat(np.arange(p["n"]), np.diff(A.indptr))
+    D, E = np.ones(p["n"]), np.ones(p["m"])
+    for _ in range(10):
+        a = np.abs(A.data)
+        Dt = np.zeros(p["n"]); np.maximum.at(Dt, cols, a)
+        Et = np.zeros(p["m"]); np.maximum.at(Et, A.indices, a)
+        Dt[Dt < 1e-9] = 1.0; Et[Et < 1e-9] = 1.0
+        Dt, Et = 1.0 / np.sqrt(Dt), 1.0 / np.sqrt(Et)
+        A.data *= Et[A.indices]
+        A.data *= Dt[cols]
+        D *= Dt; E *= Et
+    assert np.array_equal(o.vec("D"), D) and np.array_equal(o.vec("E"), E)
+    o.close()
