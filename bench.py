@@ -87,10 +87,34 @@ def allreduce(dist, vals, op="sum"):
 
 # ---- CPU baselines: the oracle timed on this host's cores, bounded samples ----------------------------------------
 def host_cores():
+    """CPU share of this process: min(affinity mask, cgroup quota); QPDO_BENCH_CORES overrides.  A GPU box shows all 256
+    hardware threads in the affinity mask while a one-GPU lease is entitled to 16 of them: without a cgroup quota to
+    read, a mask wider than 64 is taken to be such a shared host and the share of one GPU (16) is used."""
+    env = os.environ.get("QPDO_BENCH_CORES")
+    if env:
+        return max(1, int(env))
     try:
-        return len(os.sched_getaffinity(0))
+        aff = len(os.sched_getaffinity(0))
     except Exception:
-        return os.cpu_count() or 1
+        aff = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            if quota:
+                break
+        except Exception:
+            pass
+    if quota:
+        return max(1, min(aff, int(quota + 0.5)))
+    return aff if aff <= 64 else 16
 
 
 def cpu_baseline_single(prob, seconds, mode):

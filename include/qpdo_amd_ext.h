@@ -64,6 +64,9 @@ typedef struct {
     long   lowrank_rejects; /* low-rank solves abandoned for a refactorization (ill-conditioned downdate)          */
     long   pcg_soft_accepts;/* PCG solves that stopped at the iteration cap or stagnated and were accepted because their relative
                              * residual was <= 1e-8; a worse or NaN residual ends qpdo_solve with status QPDO_ERROR instead      */
+    long   collectives;     /* all-reduces issued by a row-partitioned solve (0 on one GPU)                                        */
+    long   inner_solves, inner_steps, inner_collectives;   /* Schur mode: inner (preconditioner) solves, the iterations launched for them,
+                             * and the all-reduces they issued: exactly one per launched iteration plus one per solve              */
     long   chain_fallbacks; /* dense triangular solves redone with the stepwise kernels (dense LDL')                  */
     double pcg_max_relres;  /* largest ||r||/||rhs|| a PCG solve of the last qpdo_solve ended with (tolerance QPDO_PCG_TOL)      */
 } QPDOAmdStats;

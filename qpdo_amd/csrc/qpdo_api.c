@@ -303,7 +303,7 @@ static c_float *vec_dup(const c_float *a, size_t n) {
  * qpdo_setup).  An RCCL unique id creates exactly ONE communicator: the qpdo_setup that consumes it clears it, and a
  * further distributed setup without a fresh qpdo_amd_dist_config fails with a message instead of hanging in
  * ncclCommInitRank on a spent id.  The host-callback mode has no such limit. */
-static QdevDist g_dist = {0, 1, 0, 0, 0, 0, NULL, NULL, {0}};
+static QdevDist g_dist = {0, 1, 0, 0, 0, 0, NULL, NULL, {0}, 0};
 static int g_dist_has_id = 0, g_dist_id_spent = 0;
 static pthread_mutex_t g_dist_mu = PTHREAD_MUTEX_INITIALIZER;
 int qpdo_amd_dist_config(int rank, int world, const void *rccl_unique_id, qpdo_amd_allreduce_fn fn, void *ctx) {
@@ -314,6 +314,8 @@ int qpdo_amd_dist_config(int rank, int world, const void *rccl_unique_id, qpdo_a
     g_dist.rank = rank; g_dist.world = world; g_dist.fn = (qdev_allreduce_fn)fn; g_dist.ctx = ctx;
     g_dist_has_id = 0; g_dist_id_spent = 0;
     if (rccl_unique_id && !fn) { memcpy(g_dist.nccl_id, rccl_unique_id, 128); g_dist_has_id = 1; }
+    /* world == 1 with a communicator: a forced single-rank partition -- every collective call site runs (on one GPU) */
+    g_dist.force = (world == 1 && (fn || rccl_unique_id)) ? 1 : 0;
     pthread_mutex_unlock(&g_dist_mu);
     return 0;
 }
@@ -322,7 +324,7 @@ static int dist_take(QdevDist *out) {
     int rc = 0;
     pthread_mutex_lock(&g_dist_mu);
     *out = g_dist;
-    if (g_dist.world > 1 && !g_dist.fn) {
+    if ((g_dist.world > 1 || g_dist.force) && !g_dist.fn) {
         if (!g_dist_has_id || g_dist_id_spent) rc = -1;
         else g_dist_id_spent = 1;
     }
@@ -425,7 +427,7 @@ QPDOWorkspace *qpdo_setup(const QPDOData *data, const QPDOSettings *settings) {
             QPDO_EPRINT("the RCCL unique id of qpdo_amd_dist_config has already created a communicator: call qpdo_amd_dist_config "
                         "with a fresh id before setting up another row-partitioned workspace"); goto fail;
         }
-        if (dd.world <= 1) {
+        if (dd.world <= 1 && !dd.force) {
             rc = qdev_create(&work->chol->dev, device, (int32_t)n, (int32_t)m, &a, &t, &qf, work->data->q, work->data->l, work->data->u);
         } else {
             /* row partition: rows [m0, m0+mloc) of A, the same columns of A', rows [n0, n0+nloc) of Q */
@@ -827,6 +829,8 @@ int qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out) {
     out->lowrank_rejects = (long)st.lowrank_rejects;
     out->pcg_soft_accepts = (long)st.pcg_soft_accepts;
     out->chain_fallbacks = (long)st.chain_fallbacks;
+    out->collectives = (long)st.collectives; out->inner_solves = (long)st.inner_solves;
+    out->inner_steps = (long)st.inner_steps; out->inner_collectives = (long)st.inner_collectives;
     out->pcg_max_relres = st.pcg_max_relres;
     return 0;
 }

@@ -47,6 +47,8 @@ typedef struct {
     int64_t lowrank_sweeps;     /* refinement sweeps of those solves (each one kept-factor solve + 3 SpMV) */
     int64_t lowrank_rejects;    /* low-rank solves abandoned for a refactorization (tiny pivot)   */
     int64_t pcg_soft_accepts;   /* PCG solves that hit the iteration cap / stagnated but were accepted (rel. residual <= 1e-8) */
+    int64_t collectives;        /* all-reduces issued (row-partitioned solves)                                   */
+    int64_t inner_solves, inner_steps, inner_collectives;   /* Schur mode: inner solves, their iterations launched, their all-reduces */
     int64_t chain_fallbacks;    /* dense solves redone stepwise after a polled triangular solve lost a producer */
     double  pcg_max_relres;     /* largest relative residual ||r|| / ||rhs|| any PCG solve of the last qpdo_solve ended with   */
 } QdevStats;
@@ -67,6 +69,7 @@ typedef struct {
     int32_t n0, nloc;        /* rows of Q applied by this rank inside PCG        */
     qdev_allreduce_fn fn; void *ctx;
     unsigned char nccl_id[128];
+    int force;               /* world == 1 but run the collective code path anyway (exercises the RCCL branch on one GPU) */
 } QdevDist;
 /* Ar: local rows (mloc x n); At: local columns (n x mloc, column indices local); Qf: full Q; Qs: rows [n0, n0+nloc) of Q */
 int qdev_create_dist(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsr *Ar, const QdevCsr *At, const QdevCsr *Qf,

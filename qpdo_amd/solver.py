@@ -91,7 +91,8 @@ class Stats(C.Structure):
                 ("spmv_Q_avg_s", C.c_double), ("spmv_Q_samples", C.c_long),
                 ("spmv_Ac_time_s", C.c_double), ("spmv_Ac_bytes", C.c_double), ("spmv_Ac_samples", C.c_long),
                 ("schur_passes", C.c_long), ("lowrank_solves", C.c_long), ("lowrank_cols", C.c_long), ("lowrank_sweeps", C.c_long),
-                ("lowrank_rejects", C.c_long), ("pcg_soft_accepts", C.c_long), ("chain_fallbacks", C.c_long),
+                ("lowrank_rejects", C.c_long), ("pcg_soft_accepts", C.c_long), ("collectives", C.c_long), ("inner_solves", C.c_long),
+                ("inner_steps", C.c_long), ("inner_collectives", C.c_long), ("chain_fallbacks", C.c_long),
                 ("pcg_max_relres", C.c_double)]
 
 
@@ -425,12 +426,20 @@ ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_long, C.
 _dist_keep = []
 
 
-def dist_config(rank, world, mode="rccl", group=None):
+def dist_config(rank, world, mode="rccl", group=None, force=False):
     """Partition the rows of A over `world` ranks for the workspaces created next in this process.
     mode 'rccl': all-reduce with RCCL on the solver stream (one GPU per rank); the unique id is created by rank 0
     and broadcast over torch.distributed.  mode 'host': all-reduce through torch.distributed on host buffers
     (gloo) - slow, for tests of the partition logic on a single GPU."""
     L = lib()
+    if world <= 1 and force and mode == "rccl":
+        # a single-rank RCCL communicator: the partition is the whole problem, but every collective call site of the
+        # row-partitioned solver runs through ncclAllReduce on the solver's stream (tests of the RCCL branch on one GPU)
+        uid = C.create_string_buffer(128)
+        if L.qpdo_amd_dist_unique_id(uid) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        _dist_keep.append(uid)
+        return L.qpdo_amd_dist_config(0, 1, C.cast(uid, C.c_void_p), None, None)
     if world <= 1:
         return L.qpdo_amd_dist_config(0, 1, None, None, None)
     import torch

@@ -30,8 +30,10 @@ for name, p, st in [("C1", problems.config_qp("C1"), dict(max_iter=200)),
             err = 0.0
         else:
             err = float(max(np.abs(r["x"] - ro["x"]).max(), np.abs(r["y"] - ro["y"]).max()))
-        out.append(dict(name=name, ok_counts=bool(ok_counts), err=err, status=r["info"]["status_val"], linsolve=r["stats"]["linsolve"],
-                        schur_passes=r["stats"]["schur_passes"]))
+        st_ = r["stats"]
+        out.append(dict(name=name, ok_counts=bool(ok_counts), err=err, status=r["info"]["status_val"], linsolve=st_["linsolve"],
+                        schur_passes=st_["schur_passes"], collectives=st_["collectives"], inner_solves=st_["inner_solves"],
+                        inner_steps=st_["inner_steps"], inner_collectives=st_["inner_collectives"]))
         o.close()
     # every rank must hold the same solution
     chk = np.nan_to_num(np.concatenate([r["x"], r["y"]]))

@@ -25,9 +25,13 @@ def test_row_partitioned_solve_matches_oracle(world, gpu_required):
         assert r["ok_counts"], r
         assert r["err"] <= 1e-8, r
         assert r["linsolve"] == 0
-    # the larger instance must have gone through the row-partitioned Schur-complement mode (global compact index space,
-    # two all-reduces per inner iteration)
-    assert [r for r in res if r["name"] == "schur"][0]["schur_passes"] > 0
+    # the larger instance must have gone through the row-partitioned Schur-complement mode: k-vectors partitioned, ONE
+    # collective per inner iteration (the n-vector of A_c' u with the three CG scalars appended) plus one per inner solve
+    # for the first application of S' 
+    sch = [r for r in res if r["name"] == "schur"][0]
+    assert sch["schur_passes"] > 0 and sch["inner_steps"] > 0
+    assert sch["inner_collectives"] == sch["inner_steps"] + sch["inner_solves"]
+    assert sch["collectives"] > sch["inner_collectives"]
 
 
 def test_sharded_batch_two_processes_bit_identical_to_oracle(gpu_required):
@@ -45,3 +49,40 @@ def test_sharded_batch_two_processes_bit_identical_to_oracle(gpu_required):
         assert rk["indices"] == list(range(k, 24, 2)) and rk["failed"] == 0
         for it in rk["items"]:
             assert it["counts_equal"] and it["bit_identical"], it
+
+
+def test_rccl_backend_runs_on_a_single_rank_communicator(gpu_required):
+    """The RCCL branch of the exchange (ncclCommInitRank + ncclAllReduce on the solver's stream) cannot be shared by two
+    ranks on one GPU, so it is exercised with a forced world-1 communicator: the partition is the whole problem and every
+    collective call site of the row-partitioned solver -- Ruiz norms, A x, A'y, the K products, the one all-reduce per
+    inner iteration of the Schur-complement mode -- goes through ncclAllReduce.  Results must equal the oracle's, and a
+    second workspace on the spent unique id must be refused with a message (not hang)."""
+    code = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+os.environ["QPDO_DEVICE"] = "0"
+import numpy as np
+from oracle import binding as ob
+from qpdo_amd import problems, solver
+assert solver.dist_config(0, 1, mode="rccl", force=True) == 0
+p = problems.random_qp(61, 700, 1400, 0.03, 0)
+r = solver.solve_problem(p, verbose=0)
+o = ob.OracleSolver(p, ob.default_settings()); ro = o.solve(); o.close()
+second = "ok"
+try:
+    solver.solve_problem(problems.config_qp("C1b"), verbose=0)
+except RuntimeError as e:
+    second = "refused"
+print(json.dumps(dict(counts=[r["info"][k] == ro["info"][k] for k in ("status_val", "iterations", "oterations")],
+                      err=float(max(np.abs(r["x"] - ro["x"]).max(), np.abs(r["y"] - ro["y"]).max())),
+                      stats={k: r["stats"][k] for k in ("linsolve", "schur_passes", "collectives", "inner_steps", "inner_solves", "inner_collectives")},
+                      second=second)))
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert all(r["counts"]) and r["err"] <= 1e-8, r
+    st = r["stats"]
+    assert st["linsolve"] == 0 and st["schur_passes"] > 0 and st["collectives"] > 0
+    assert st["inner_collectives"] == st["inner_steps"] + st["inner_solves"]
+    assert r["second"] == "refused"
