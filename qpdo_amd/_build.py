@@ -82,7 +82,13 @@ def build_lib(force=False, verbose=False):
 
 def ensure_lib():
     """Path of the product library; builds it when the sources are newer.  Never falls back
-    to anything else: a missing library is an error."""
+    to anything else: a missing library is an error.  (QPDO_AMD_LIB: an explicitly named build of the same library,
+    for A/B timing of two versions on one box; tools/ab_c4.py.)"""
+    override = os.environ.get("QPDO_AMD_LIB")
+    if override:
+        if not os.path.exists(override):
+            raise RuntimeError("QPDO_AMD_LIB=%s does not exist" % override)
+        return override
     if os.path.exists(LIB_PATH) and not _stale(LIB_PATH, HIP_SOURCES + C_SOURCES + HEADERS):
         return LIB_PATH
     if hipcc() is None:
