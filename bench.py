@@ -303,7 +303,7 @@ def main():
     last = r
     rp, rd = problems.kkt_residuals(prob, last["x"], last["y"]) if last["info"]["status_val"] not in (-3, -4) else (None, None)
     # roofline of the dominant kernel, live HIP-event samples from the timed solves.  With the Schur-complement mode
-    # of the PCG the bulk of the time is the inner solves' A_c product (k_spmv_slab<EpiSchurA>: the k active rows of A,
+    # of the PCG the bulk of the time is the inner solves' A_c product (k_spmv_slab<EpiSchurW>: the k active rows of A,
     # compact index space, k changes per pass, so bytes and time are summed over the samples); otherwise it is the Q
     # product of the PCG operator (k_spmv_slab<EpiPcgQ>).  A back-to-back micro-benchmark of the full-size kernel beside it.
     def load_profile(name):
@@ -320,20 +320,18 @@ def main():
     elif ac_n > at_n and ac_time > 0:
         bench_t, full_bytes = s.bench_spmv(0, reps=20)
         achieved = ac_bytes / ac_time / 1e9
-        roof = dict(bound="hbm", kernel="k_spmv_slab<EpiSchurA> (S'p = p/d + A_c t: the active rows of A in the pass's compact index space)",
+        roof = dict(bound="hbm", kernel="k_spmv_slab<EpiSchurW> (w = u/d + A_c t, product 2 of S' u: the active rows of A in the pass's compact index space)",
                     achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
                     alg_bytes_per_launch=ac_bytes / ac_n, avg_launch_s=ac_time / ac_n, samples=int(ac_n),
                     microbench_GBs=full_bytes / bench_t / 1e9, spmv_A_GBs=None, spmv_At_GBs=None)
         if a.workload == "C4":
             # HBM bytes per launch from the PMC counters cannot be collected inside this process: the figure is the average over
             # all real launches of this kernel in separate rocprofv3 --pmc passes over this same command (committed summary)
-            for name in ("r02_pmc_schur_inner_c4.json", "r01_pmc_schur_inner_c4.json"):
-                pin = load_profile(name)
-                if pin is not None:
-                    roof["traffic"] = pin["k_spmv_slab<EpiSchurA> (A_c product)"]["traffic_bytes_avg"]
-                    roof["traffic_source"] = ("profiles/%s: 2*FETCH_SIZE + WRITE_SIZE averaged over the real launches of this kernel in "
-                                              "separate rocprofv3 --pmc passes over this command" % name)
-                    break
+            pin = load_profile("r02_pmc_schur_inner_c4.json")
+            if pin is not None and "k_spmv_slab<EpiSchurW>" in pin:
+                roof["traffic"] = pin["k_spmv_slab<EpiSchurW>"]["traffic_bytes_avg"]
+                roof["traffic_source"] = ("profiles/r02_pmc_schur_inner_c4.json: 2*FETCH_SIZE + WRITE_SIZE averaged over the %d real launches of this "
+                                          "kernel in separate rocprofv3 --pmc passes over this command" % pin["k_spmv_slab<EpiSchurW>"]["real_launches"])
         if at_n:
             q_t, q_b = s.bench_spmv(2, reps=5)
             roof["spmv_Q_live_GBs"] = q_b / (at_time / at_n) / 1e9
