@@ -228,20 +228,23 @@ def run_batch(a, rank, world, dist):
 
 
 def small_kernel_roofline(newton_passes, seconds, n_gpus):
-    """k_small_solve keeps a QP's whole state in LDS: it is bound by LDS traffic and barrier latency, not by HBM.
-    Stated model (DESIGN.md section 3): per Newton pass the in-LDS LDL' reads/writes ~ (2/3) n^3 + m n^2 ... bytes of LDS;
-    reported here as achieved LDS GB/s against the 256-CU aggregate LDS peak."""
+    """What bounds k_small_solve: not HBM (the problem data once, ~70 KB per QP) and not LDS bandwidth
+    (a few % of the aggregate), but the LATENCY of dependent, barrier-separated steps: a Newton pass walks about
+    m + 4n + 55 of them (assembly row by row, two per factor column, the two triangular solves, the bitonic sort stages);
+    bit-identity with the oracle fixes the operation order that makes them dependent.  achieved = ns per step of one
+    workgroup (two interleaved per CU), floor = barrier + LDS round trip + a dozen dependent operations."""
     n, m = 120, 360
-    # per Newton pass, fp64 words moved through LDS (reads + writes), dominant terms:
-    #   assembly A'DA: m_active ~ m/2 rows x (nnz_row^2) ~ small; factor: n^3/3 MAC -> 2 reads + 1 write per MAC / reuse 1
-    lds_bytes = 8.0 * (n ** 3)            # ~3 LDS words per MAC x n^3/3 MACs (right-looking update streams the trailing block)
-    lds_bytes += 8.0 * 4 * n * n          # two triangular solves + K assembly read-modify-write
-    lds_bytes += 8.0 * 2 * m * 12 * 10    # bitonic sort of 2m keys: log^2 passes (~55) x 2m x 16 B, order of magnitude
-    peak = 256 * 128 * 2.4                # GB/s: 256 CUs x 128 B/clk x 2.4 GHz (MI355X_MICROARCH.md LDS section)
-    ach = newton_passes * lds_bytes / seconds / 1e9 / max(1, n_gpus)
-    return dict(bound="lds", kernel="k_small_solve (one workgroup per QP, whole state in LDS)", achieved=ach, peak=peak, unit="GB/s",
-                frac=ach / peak, traffic=None,
-                note="LDS-traffic model, not an HBM roofline: HBM traffic of this kernel is the problem data once (~70 KB per QP)")
+    steps = m + 4 * n + 55
+    wgs = 512 * max(1, n_gpus)                     # workgroups in flight: 2 per CU x 256 CUs per GPU
+    ns_per_step = seconds * wgs / max(1.0, newton_passes) / steps * 1e9
+    floor = 250.0
+    lds_bytes = 8.0 * (n ** 3) + 8.0 * 4 * n * n + 16.0 * 2 * m * 55
+    lds_peak = 256 * 128 * 2.4 * max(1, n_gpus)    # GB/s
+    return dict(bound="latency", kernel="k_small_solve (one workgroup per QP, whole state in LDS)", achieved=ns_per_step, peak=floor,
+                unit="ns per dependent step", frac=floor / ns_per_step if ns_per_step > 0 else None, traffic=None,
+                steps_per_newton_pass=steps, ms_per_newton_pass_per_workgroup=ns_per_step * steps * 1e-6,
+                lds_bandwidth_frac=(newton_passes * lds_bytes / seconds / 1e9) / lds_peak,
+                note="latency-bound; HBM traffic is the problem data once, LDS bandwidth use is a few percent")
 
 
 def main():
