@@ -81,6 +81,9 @@ int  qpdo_amd_sync(QPDOWorkspace *work);
 /* HIP-event timing of the SpMV kernel on the workspace's own (scaled) matrices.
  * which: 0 = A (CSR m x n), 1 = A' (CSR n x m), 2 = Q (full symmetric CSR). */
 int  qpdo_amd_bench_spmv(QPDOWorkspace *work, int which, int reps, double *avg_seconds, double *alg_bytes);
+/* HIP-event timing of the dense LDL' factorization (n <= QPDO_DENSE_MAX_N) with the workspace's current weights; *check
+ * (optional) receives the relative residual of one solve with the fresh factor */
+int  qpdo_amd_bench_dense_factor(QPDOWorkspace *work, int reps, double *avg_seconds, double *check);
 /* y = M v on the device, host in/out (parity tests) */
 int  qpdo_amd_spmv(QPDOWorkspace *work, int which, const double *v, double *y);
 /* root of eta t + beta + delta'[delta t - alpha]_+ over 2m breakpoints (reference

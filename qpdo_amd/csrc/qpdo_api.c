@@ -803,6 +803,9 @@ int qpdo_amd_get_trace(const QPDOWorkspace *work, const QPDOAmdTraceRec **recs, 
 int qpdo_amd_bench_spmv(QPDOWorkspace *work, int which, int reps, double *avg_seconds, double *alg_bytes) {
     return qdev_bench_spmv(work->chol->dev, which, reps, avg_seconds, alg_bytes);
 }
+int qpdo_amd_bench_dense_factor(QPDOWorkspace *work, int reps, double *avg_seconds, double *check) {
+    return qdev_bench_dense_factor(work->chol->dev, reps, avg_seconds, check);
+}
 int qpdo_amd_spmv(QPDOWorkspace *work, int which, const double *v, double *y) { return qdev_spmv(work->chol->dev, which, v, y); }
 int qpdo_amd_linesearch(QPDOWorkspace *work, double eta, double beta, const double *delta, const double *alpha, double *tau) {
     return qdev_linesearch(work->chol->dev, eta, beta, delta, alpha, tau);

@@ -140,6 +140,8 @@ int qdev_get_ac_sample(QpdoDev *d, double *seconds_sum, double *bytes_sum, long 
  * events on the backend stream.  which: 0 A (CSR m x n), 1 A' (CSR n x m), 2 Q.
  * Returns average seconds per launch and the algorithmic bytes of one launch. */
 int qdev_bench_spmv(QpdoDev *d, int which, int reps, double *avg_seconds, double *alg_bytes);
+/* dense LDL' factorization with the current weights, timed with HIP events; optional residual check of one solve */
+int qdev_bench_dense_factor(QpdoDev *d, int reps, double *avg_seconds, double *check);
 /* standalone SpMV for parity tests: y = M v */
 int qdev_spmv(QpdoDev *d, int which, const double *v_host, double *y_host);
 /* standalone piecewise-affine linesearch for parity tests (2m entries) */

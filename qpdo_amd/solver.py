@@ -103,7 +103,7 @@ class BatchItem(C.Structure):
 
 
 EXT_SYMBOLS = ["qpdo_amd_dist_config", "qpdo_amd_dist_unique_id", "qpdo_amd_solve_batch", "qpdo_amd_device_count", "qpdo_amd_last_error", "qpdo_amd_get_stats", "qpdo_amd_get_trace",
-               "qpdo_amd_sync", "qpdo_amd_bench_spmv", "qpdo_amd_spmv", "qpdo_amd_linesearch", "qpdo_amd_download"]
+               "qpdo_amd_sync", "qpdo_amd_bench_spmv", "qpdo_amd_bench_dense_factor", "qpdo_amd_spmv", "qpdo_amd_linesearch", "qpdo_amd_download"]
 
 _lib = None
 
@@ -130,6 +130,7 @@ def lib():
         L.qpdo_amd_sync.argtypes = [W]
         L.qpdo_amd_bench_spmv.argtypes = [W, C.c_int, C.c_int, dp, dp]
         L.qpdo_amd_spmv.argtypes = [W, C.c_int, dp, dp]
+        L.qpdo_amd_bench_dense_factor.argtypes = [W, C.c_int, dp, dp]
         L.qpdo_amd_linesearch.argtypes = [W, C.c_double, C.c_double, dp, dp, dp]
         L.qpdo_amd_download.argtypes = [W, C.c_int, dp]
         L.qpdo_amd_dist_config.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -292,6 +293,13 @@ class QPDO:
         if rc:
             raise RuntimeError(lib().qpdo_amd_last_error().decode())
         return t.value, b.value
+
+    def bench_dense_factor(self, reps=5, check=True):
+        t, c = C.c_double(0), C.c_double(0)
+        rc = lib().qpdo_amd_bench_dense_factor(self._w, reps, C.byref(t), C.byref(c) if check else None)
+        if rc:
+            raise RuntimeError(lib().qpdo_amd_last_error().decode())
+        return t.value, c.value
 
     def spmv(self, which, v):
         v = np.ascontiguousarray(v, np.float64)
