@@ -49,6 +49,25 @@ def test_struct_layout_sizes():
     assert C.sizeof(solver.CholmodSparse) == 8 * 8 + 6 * 4
 
 
+def test_ctypes_mirror_has_the_reference_member_offsets():
+    """qpdo_amd/solver.py mirrors include/qpdo.h by hand: pin every member offset the C caller's _Static_asserts pin
+    (tests/abi_driver.c; reference include/types.h, DLONG + PROFILING layout)"""
+    W = solver.QPDOWorkspace
+    exp = dict(data=0, x=8, y=16, Ax=24, initialized=48, temp_m=56, mu=80, sqrt_mu_min=96, n_mu_changed=112, sigma=120, norm_q=136,
+               xbar=144, dx=160, dy=168, tau=176, Qdx=184, w=208, linsys_rhs=272, res_prim_norm_old=280, ls_eta=296, ls_taus=328,
+               eps_prim=360, eps_in=392, D_temp=400, chol=416, settings=424, scaling=432, solution=440, info=448, timer=456)
+    for k, v in exp.items():
+        assert getattr(W, k).offset == v, k
+    assert C.sizeof(W) == 464
+    I = solver.QPDOInfo
+    for k, v in dict(iterations=0, oterations=8, status=16, status_val=48, res_prim_norm=56, objective=88, setup_time=96, solve_time=104,
+                     run_time=112).items():
+        assert getattr(I, k).offset == v, k
+    S = solver.QPDOSettings
+    for k, v in dict(max_time=0, max_iter=8, eps_abs=24, proximal=88, scaling=120, reset_newton_iter=144).items():
+        assert getattr(S, k).offset == v, k
+
+
 def test_setup_returns_null_on_invalid_input(capfd):
     p = problems.config_qp("C1b")
     with pytest.raises(RuntimeError):          # l > u: validate_data (reference src/validate.c:20-28)

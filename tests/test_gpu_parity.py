@@ -539,3 +539,48 @@ def test_constructed_primal_infeasible_instance(linsolve, gpu_required):
     dy = r["prim_inf_cert"]
     assert np.abs(p["A"].T @ dy).max() <= 1e-5 * np.abs(dy).max()
     o.close()
+
+
+def test_fused_batch_honours_max_time_and_fills_times(gpu_required):
+    """round-1 advisor finding: the fused one-workgroup-per-QP path ignored settings->max_time and left the PROFILING times
+    of QPDOInfo at zero.  Reference: src/qpdo.c:441-447 (checked at the end of every pass), :461-464."""
+    probs = [problems.config_qp("C3", i) for i in range(8)]
+    res, failed = solver.solve_batch(probs, verbose=0)
+    assert failed == 0
+    for r in res:
+        i = r["info"]
+        assert i["status_val"] == 1 and i["solve_time"] > 0 and i["setup_time"] > 0
+        assert abs(i["run_time"] - (i["setup_time"] + i["solve_time"])) <= 1e-12
+    res, failed = solver.solve_batch(probs, verbose=0, max_time=1e-7)
+    assert failed == 0
+    for r in res:
+        assert r["info"]["status_val"] == -6 and r["info"]["status"] == "max time exceeded"
+        assert r["info"]["iterations"] == 0                    # stopped at the end of pass 0, iter not advanced (qpdo.c:441-447)
+
+
+def test_batch_with_inconsistent_dimensions_is_rejected_not_indexed(gpu_required, capfd):
+    """round-1 advisor finding: qdev_small_eligible skipped the checks of qpdo_setup.  An item whose Q is not n x n must take
+    the generic path, which refuses it (QPDO_ERROR for that item) -- the other items are still solved"""
+    import scipy.sparse as sp
+    probs = [problems.config_qp("C3", i) for i in range(3)]
+    bad = dict(probs[1]); bad["Q"] = sp.csc_matrix(sp.eye(50)); probs[1] = bad      # 50 x 50 against n = 120
+    res, failed = solver.solve_batch(probs, verbose=0)
+    assert failed == 1
+    assert res[1]["info"]["status_val"] == -99
+    assert res[0]["info"]["status_val"] == 1 and res[2]["info"]["status_val"] == 1
+    assert "dimensions do not match" in capfd.readouterr().out
+
+
+def test_pcg_that_cannot_converge_is_an_error_not_a_silent_step(gpu_required, monkeypatch):
+    """round-1 advisor finding: pcg_solve returned 0 whether or not CG converged.  With an iteration cap far below what the
+    Newton systems need, the solve must end with QPDO_ERROR and a message, never continue on an arbitrary dx"""
+    monkeypatch.setenv("QPDO_LINSOLVE", "pcg")
+    monkeypatch.setenv("QPDO_PCG_SCHUR", "0")
+    monkeypatch.setenv("QPDO_PCG_MAXIT", "3")
+    p = problems.random_qp(22, 150, 300, 0.05, 0)
+    r = solver.solve_problem(p, verbose=0)
+    assert r["info"]["status_val"] == -99
+    assert "did not converge" in solver.lib().qpdo_amd_last_error().decode()
+    monkeypatch.delenv("QPDO_PCG_MAXIT")
+    r = solver.solve_problem(p, verbose=0)
+    assert r["info"]["status_val"] == 1 and r["stats"]["pcg_soft_accepts"] == 0 and r["stats"]["pcg_max_relres"] <= 1e-12
