@@ -21,6 +21,8 @@
  *   QPDO_PCG_INNER_F32  "1": the Schur mode's inner (preconditioner) solve streams an fp32 copy of the compact matrix values;
  *                    vectors, accumulation and the outer CG on the exact K stay fp64 (opt-in, default off)
  *   QPDO_PCG_TOL     relative residual tolerance of the Jacobi-PCG solve (default 1e-12)
+ *   QPDO_PCG_ABS     factor f of the absolute stopping rule of the PCG solve: stop when the residual, in the unscaled inf-norm of
+ *                    the reference's inner dual residual, is <= f * eps_abs (default 1e-5; 0: relative rule only; proximal only)
  *   QPDO_PCG_MAXIT   PCG iteration cap per Newton step (default 100000)
  *   QPDO_FIX_STATUS_RESET  "1": reset info->status_val at the start of qpdo_solve
  *                    (the reference does not: src/qpdo.c:451-453 vs :200)

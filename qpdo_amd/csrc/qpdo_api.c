@@ -578,6 +578,7 @@ void qpdo_solve(QPDOWorkspace *work) {
     c_int iter = 0, oter = 0, iter_old = 0;
     if (!work->initialized) goto done;      /* warm start failed on the device */
     DEVCALL(qdev_begin_solve(dev));
+    DEVCALL(qdev_set_eps_abs(dev, s->eps_abs));
 
     for (iter = 0; iter < s->max_iter; iter++) {
         QdevResid r;
