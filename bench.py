@@ -164,9 +164,9 @@ def cpu_baseline_batch(probs, seconds, settings_over):
         while True:
             with lock:
                 i = state["next"]; state["next"] += 1
-            if i >= len(probs) or time.time() - t0 > seconds:
+            if time.time() - t0 > seconds:
                 return
-            o = ob.OracleSolver(probs[i], ob.default_settings(**settings_over))
+            o = ob.OracleSolver(probs[i % len(probs)], ob.default_settings(**settings_over))
             o.solve()
             inf = o.info()
             o.close()
@@ -177,7 +177,7 @@ def cpu_baseline_batch(probs, seconds, settings_over):
     [t.join() for t in th]
     dt = time.time() - t0
     return dict(value=state["newton"] / dt, unit="newton_iters/s", cores=cores, kind="port", qps_per_s=state["qps"] / dt,
-                sample="%d of the batch's QPs through the oracle (dense LDL' per QP, setup + solve), %d host threads, %.1f s" % (state["qps"], cores, dt))
+                sample="%d solves over a %d-QP slice of the batch through the oracle (dense LDL' per QP, setup + solve), %d host threads, %.1f s" % (state["qps"], len(probs), cores, dt))
 
 
 # ---- workloads -----------------------------------------------------------------------------------------------------
@@ -196,9 +196,11 @@ def run_batch(a, rank, world, dist):
     barrier(dist)
     t0 = time.time()
     newton = solved = failed = 0
+    kernel_s = 0.0
     for _ in range(a.steps):
         res, f = B.run(**st)
         failed += f
+        kernel_s += B.kernel_seconds
         newton += sum(r["info"]["iterations"] - r["info"]["oterations"] for r in res)
         solved += sum(r["info"]["status_val"] == 1 for r in res)
     barrier(dist)
@@ -219,16 +221,17 @@ def run_batch(a, rank, world, dist):
                                                        (", max_iter=%d" % a.max_iter) if a.max_iter > 0 else " (max_iter=10000)"),
                    "count": count, "n": cfg["n"], "m": cfg["m"], "parallelism": "independent QPs, batch sharded over ranks, no collective"},
         "qps_per_s": tot_items / dt_max, "solved": tot_solved, "failed": tot_failed, "items": tot_items, "generate_s": t_gen,
-        "roofline": small_kernel_roofline(tot_newton / max(1, a.steps), dt_max / max(1, a.steps), world),
+        "kernel_s_per_step_rank0": kernel_s / max(1, a.steps),
+        "roofline": small_kernel_roofline(newton / max(1, a.steps), kernel_s / max(1, a.steps), 1),       # rank 0's launch
     }
     if world == 1 and not a.no_cpu_baseline:
-        sl = [problems.config_qp("C3", i) for i in range(min(count, 512))]
-        out["cpu_baseline"] = cpu_baseline_batch(sl, a.cpu_seconds, {k: v for k, v in st.items() if k != "verbose"})
+        sl = [problems.config_qp("C3", i) for i in range(min(count, 256))]
+        out["cpu_baseline"] = cpu_baseline_batch(sl, min(a.cpu_seconds, 10.0), {k: v for k, v in st.items() if k != "verbose"})
     return out
 
 
 def small_kernel_roofline(newton_passes, seconds, n_gpus):
-    """What bounds k_small_solve: not HBM (the problem data once, ~70 KB per QP) and not LDS bandwidth
+    """seconds: HIP-event duration of the kernel launch.  What bounds k_small_solve: not HBM (the problem data once, ~70 KB per QP) and not LDS bandwidth
     (a few % of the aggregate), but the LATENCY of dependent, barrier-separated steps: a Newton pass walks about
     m + 4n + 55 of them (assembly row by row, two per factor column, the two triangular solves, the bitonic sort stages);
     bit-identity with the oracle fixes the operation order that makes them dependent.  achieved = ns per step of one
@@ -260,11 +263,13 @@ def main():
         return
     cfg = problems.CONFIGS[a.workload]
     t0 = time.time()
-    rows_mode = (a.partition == "rows" and world > 1)
+    rows_mode = (a.partition == "rows")
     prob = problems.config_qp(a.workload, index=0 if rows_mode else rank)
     t_gen = time.time() - t0
     if rows_mode:      # every rank holds the same instance; the library keeps its row slice on the GPU
-        if solver.dist_config(rank, world, mode="rccl") != 0:
+        # (N = 1: a forced single-rank RCCL communicator -- the partitioned code path, every collective through ncclAllReduce,
+        # on one GPU: its time against the default path's is the overhead of the partitioned organisation itself)
+        if solver.dist_config(rank, world, mode="rccl", force=(world == 1)) != 0:
             raise RuntimeError("qpdo_amd_dist_config failed")
     st = dict(verbose=0)
     if a.max_time > 0:
@@ -315,7 +320,14 @@ def main():
                 return json.load(fh)
         except Exception:
             return None
-    if s.stats()["linsolve"] == 1:
+    if rows_mode:
+        # row-partitioned solve: the HIP-event samples of the inner products are not taken across collectives; the figure is the
+        # back-to-back micro-benchmark of this rank's slice of A (the same slab kernel the inner products use)
+        bench_t, full_bytes = s.bench_spmv(0, reps=20)
+        roof = dict(bound="hbm", kernel="k_spmv_slab<EpiStore> on this rank's rows of A (micro-benchmark)", achieved=full_bytes / bench_t / 1e9, peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=full_bytes / bench_t / 1e9 / HBM_PEAK_GBS, traffic=None, alg_bytes_per_launch=full_bytes, avg_launch_s=bench_t,
+                    spmv_A_GBs=None, spmv_At_GBs=None)
+    elif s.stats()["linsolve"] == 1:
         # dense LDL' (C2): the dominant kernel is the fp64-MFMA trailing update; MFMA utilisation comes from the committed
         # PMC profile, the live figure here is the factor's flop rate from the solve's own statistics
         roof = dict(bound="mfma", kernel="k_ldl_syrk (fp64 MFMA trailing update of the dense LDL')", achieved=None, peak=78.6, unit="TFLOP/s",
@@ -429,12 +441,12 @@ def main():
                 B.run(verbose=0, **kw)                      # warm-up (device arena, code objects)
                 t0 = time.time(); resb, failed = B.run(verbose=0, **kw); dtb = time.time() - t0
                 nwt = sum(r_["info"]["iterations"] - r_["info"]["oterations"] for r_ in resb)
-                c3[label] = dict(seconds=dtb, qps_per_s=nb / dtb, failed=failed, newton_iters_per_s=nwt / dtb,
+                c3[label] = dict(seconds=dtb, kernel_seconds=B.kernel_seconds, qps_per_s=nb / dtb, failed=failed, newton_iters_per_s=nwt / dtb,
                                  solved=sum(r_["info"]["status_val"] == 1 for r_ in resb),
-                                 roofline=small_kernel_roofline(nwt, dtb, 1))
+                                 roofline=small_kernel_roofline(nwt, B.kernel_seconds, 1))
             c3["workload"] = "%d QPs n=120, m=360 (120 equality rows), one fused-kernel launch, wall time through the Python class" % nb
             if not a.no_cpu_baseline:
-                c3["cpu_baseline"] = cpu_baseline_batch(probs[:512], 10.0, {})
+                c3["cpu_baseline"] = cpu_baseline_batch(probs[:256], 8.0, {})
             out["other_configs"]["C3_batch"] = c3
         except Exception as e:
             out.setdefault("other_configs", {})["error"] = repr(e)

@@ -125,6 +125,8 @@ typedef struct {
 } QPDOAmdBatchItem;
 /* returns the number of items whose setup failed (their info.status_val is QPDO_ERROR) */
 long qpdo_amd_solve_batch(long count, QPDOAmdBatchItem *items, const QPDOSettings *settings, int nthreads);
+/* HIP-event duration of the fused kernel launch of the last qpdo_amd_solve_batch on this process (0 if it took the threaded path) */
+double qpdo_amd_batch_kernel_seconds(void);
 
 #ifdef __cplusplus
 }

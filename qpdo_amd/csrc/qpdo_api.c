@@ -867,6 +867,7 @@ static void *batch_worker(void *arg) {
     }
     return NULL;
 }
+double qpdo_amd_batch_kernel_seconds(void) { return qdev_small_last_kernel_seconds(); }
 long qpdo_amd_solve_batch(long count, QPDOAmdBatchItem *items, const QPDOSettings *settings, int nthreads) {
     if (count <= 0) return 0;
     /* small problems: the fused one-workgroup-per-QP kernel solves the whole batch in one launch

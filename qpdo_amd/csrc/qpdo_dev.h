@@ -155,6 +155,7 @@ struct QPDOAmdBatchItem_;
 int qdev_small_eligible(long count, const void *items);
 int qdev_small_batch(int device, long count, void *items, const void *settings);
 const char *qdev_small_last_error(void);
+double qdev_small_last_kernel_seconds(void);
 
 #ifdef __cplusplus
 }

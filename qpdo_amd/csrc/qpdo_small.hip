@@ -746,6 +746,8 @@ static void parallel_items(long count, F f) {
 extern "C" {
 
 const char *qdev_small_last_error(void) { return s_err; }
+static double s_last_kernel_s = 0.0;          // HIP-event duration of the last k_small_solve launch (bench.py's latency statement)
+double qdev_small_last_kernel_seconds(void) { return s_last_kernel_s; }
 
 // 1 if every item fits the fused kernel
 int qdev_small_eligible(long count, const void *items_) {
@@ -776,7 +778,7 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
     const QPDOSettings *settings = (const QPDOSettings *)settings_;
     int rc = 0;
     std::lock_guard<std::mutex> arena_lock(s_arena_mu);
-    char *dbase = nullptr; hipStream_t stream = nullptr; SmallQP *dprobs = nullptr; long long *dprof = nullptr;
+    char *dbase = nullptr; hipStream_t stream = nullptr; SmallQP *dprobs = nullptr; long long *dprof = nullptr; hipEvent_t evk0 = nullptr, evk1 = nullptr;
     std::unique_ptr<char[]> harena, hout; std::vector<SmallQP> hp((size_t)count);
     const bool tprof = getenv("QPDO_SMALL_PROF") && !strcmp(getenv("QPDO_SMALL_PROF"), "2");
     auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
@@ -871,13 +873,17 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
         lds += (klds_ok && kbytes > lsbytes) ? kbytes : lsbytes;
         SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(budget)));
         if (const char *pad = getenv("QPDO_SMALL_LDS_MIN")) { const size_t v = (size_t)atol(pad); if (v > lds && v <= budget) lds = v; }   // occupancy experiments
+        if (!evk0) { SHIP(hipEventCreate(&evk0)); SHIP(hipEventCreate(&evk1)); }
+        SHIP(hipEventRecord(evk0, stream));
         hipLaunchKernelGGL(k_small_solve, dim3((unsigned)count), dim3(SM_THREADS), lds, stream, dprobs, (int)count, *settings, klds_ok);
+        SHIP(hipEventRecord(evk1, stream));
     }
     SHIP(hipGetLastError());
     SHIP(hipMemcpyAsync(hp.data(), dprobs, (size_t)count * sizeof(SmallQP), hipMemcpyDeviceToHost, stream));
     if (tprof) { SHIP(hipStreamSynchronize(stream)); lap("kernel"); }
     SHIP(hipMemcpyAsync(hout.get(), dbase + upload_bytes, out_bytes, hipMemcpyDeviceToHost, stream));
     SHIP(hipStreamSynchronize(stream));
+    { float ms = 0.f; if (evk0 && hipEventElapsedTime(&ms, evk0, evk1) == hipSuccess) s_last_kernel_s = (double)ms * 1e-3; }
     lap("download");
     if (dprof) {   // diagnostic: phase shares of the longest-running item
         std::vector<long long> hpf((size_t)count * PH_COUNT);
@@ -903,6 +909,8 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
 done:
     if (dprobs) (void)hipFree(dprobs);
     if (dprof) (void)hipFree(dprof);
+    if (evk0) (void)hipEventDestroy(evk0);
+    if (evk1) (void)hipEventDestroy(evk1);
     if (stream) (void)hipStreamDestroy(stream);
     return rc;
 }

@@ -102,7 +102,7 @@ class BatchItem(C.Structure):
     _fields_ = [("data", C.POINTER(QPDOData)), ("x0", dp), ("y0", dp), ("x", dp), ("y", dp), ("info", QPDOInfo)]
 
 
-EXT_SYMBOLS = ["qpdo_amd_dist_config", "qpdo_amd_dist_unique_id", "qpdo_amd_solve_batch", "qpdo_amd_device_count", "qpdo_amd_last_error", "qpdo_amd_get_stats", "qpdo_amd_get_trace",
+EXT_SYMBOLS = ["qpdo_amd_dist_config", "qpdo_amd_dist_unique_id", "qpdo_amd_solve_batch", "qpdo_amd_batch_kernel_seconds", "qpdo_amd_device_count", "qpdo_amd_last_error", "qpdo_amd_get_stats", "qpdo_amd_get_trace",
                "qpdo_amd_sync", "qpdo_amd_bench_spmv", "qpdo_amd_bench_dense_factor", "qpdo_amd_spmv", "qpdo_amd_linesearch", "qpdo_amd_download"]
 
 _lib = None
@@ -136,6 +136,7 @@ def lib():
         L.qpdo_amd_dist_config.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.qpdo_amd_dist_unique_id.argtypes = [C.c_void_p]
         L.qpdo_amd_solve_batch.restype = C.c_long
+        L.qpdo_amd_batch_kernel_seconds.restype = C.c_double
         L.qpdo_amd_solve_batch.argtypes = [C.c_long, C.POINTER(BatchItem), C.POINTER(QPDOSettings), C.c_int]
         _lib = L
     return _lib
@@ -385,6 +386,7 @@ class Batch:
         if settings is None:
             settings = default_settings(**kw)
         failed = lib().qpdo_amd_solve_batch(len(self.outs), self.items, C.byref(settings), int(nthreads))
+        self.kernel_seconds = float(lib().qpdo_amd_batch_kernel_seconds())
         names = [f for f, _ in QPDOInfo._fields_]
         res = []
         for i, (x, y) in enumerate(self.outs):

@@ -290,6 +290,120 @@ static void run_prod_wg(const char *name, int m, int n, int nwg, int budget_div,
     printf("%-44s wg %4d x %4d thr, W %5d, %2d slabs: %.3f ms  algorithmic %.2f TB/s\n", name, grid, NT, W, nslabs, ms, nnz * 12 / ms / 1e9); fflush(stdout);
     CK(hipFree(sp)); CK(hipFree(seg)); CK(hipFree(i16)); CK(hipFree(i16sm)); CK(hipFree(vsm));
 }
+// split-by-slab geometry: workgroup (rb, s) stages ONE x slab and streams the segments of slab s for the rows of `nslabs`
+// consecutive row ranges; partial row sums go to ypart[s][row]; the workgroup that arrives last for a row block adds the
+// partials in slab order and writes y (fixed order: reproducible).  Stages 1/nslabs of the x traffic of the production geometry.
+template <int TPR, int UNR>
+__global__ __launch_bounds__(1024) void k_slab_split(int nrows, int ncols, int nslabs, int W, int rows_per_wg, const int2 *__restrict__ seg,
+                                                     const unsigned short *__restrict__ i16sm, const double *__restrict__ vsm,
+                                                     const double *__restrict__ x, double *__restrict__ ypart, int *__restrict__ counters,
+                                                     double *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int next_row, is_last;
+    double *xs = lds, *acc = lds + W;
+    const int tid = threadIdx.x;
+    const int rb = blockIdx.x / nslabs, s = blockIdx.x % nslabs;
+    const int row0 = rb * nslabs * rows_per_wg;
+    const int R = max(0, min(nslabs * rows_per_wg, nrows - row0));
+    for (int r = tid; r < R; r += 1024) acc[r] = 0.0;
+    const int lane = tid & (TPR - 1);
+    {
+        const int c0 = s * W, cw = min(W, ncols - c0);
+        const int pairs = cw >> 1; const double2 *src = reinterpret_cast<const double2 *>(x + c0); double2 *dst = reinterpret_cast<double2 *>(xs);
+        for (int i = tid; i < pairs; i += 1024) dst[i] = src[i];
+        if ((cw & 1) && tid == 0) xs[cw - 1] = x[c0 + cw - 1];
+        if (tid == 0) next_row = 0;
+    }
+    __syncthreads();
+    const int gw = (tid & 63) / TPR;
+    for (;;) {
+        int base = 0;
+        if ((tid & 63) == 0) base = atomicAdd(&next_row, 64 / TPR);
+        base = __shfl(base, 0, 64);
+        if (base >= R) break;
+        const int r = base + gw;
+        if (r >= R) continue;
+        const int row = row0 + r;
+        const int2 sg = seg[(size_t)row * nslabs + s];
+        const int beg = sg.x, end = sg.x + sg.y;
+        const int kb = beg & ~1;
+        double sa[2 * UNR];
+#pragma unroll
+        for (int u = 0; u < 2 * UNR; u++) sa[u] = 0.0;
+        for (int k = kb + 2 * lane; k < end; k += 2 * UNR * TPR) {
+            double2 v[UNR]; int ax[UNR], ay[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int kk = k + u * 2 * TPR; const int kc = kk < end ? kk : kb;
+                v[u] = *reinterpret_cast<const double2 *>(vsm + kc);
+                const ushort2 a = *reinterpret_cast<const ushort2 *>(i16sm + kc); ax[u] = a.x; ay[u] = a.y;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int kk = k + u * 2 * TPR;
+                const double px = v[u].x * xs[ax[u]], py = v[u].y * xs[ay[u]];
+                sa[2 * u] += (kk >= beg && kk < end) ? px : 0.0;
+                sa[2 * u + 1] += (kk + 1 < end) ? py : 0.0;
+            }
+        }
+        double t = 0.0;
+#pragma unroll
+        for (int u = 0; u < 2 * UNR; u++) t += sa[u];
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1) t += __shfl_down(t, o, TPR);
+        if (lane == 0) acc[r] = t;
+    }
+    __syncthreads();
+    // hand-off without cache-wide fences: the partials leave with agent-scope (sc1, write-through) stores, the barrier drains
+    // them, one relaxed agent-scope add publishes; the last arriver reads them back with agent-scope (sc1) loads
+    for (int r = tid; r < R; r += 1024) __hip_atomic_store(&ypart[(size_t)s * nrows + row0 + r], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(&counters[rb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (old == nslabs - 1);
+        if (is_last) __hip_atomic_store(&counters[rb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    for (int r = tid; r < R; r += 1024) {
+        double t = 0.0;
+        for (int q = 0; q < nslabs; q++) t += __hip_atomic_load(&ypart[(size_t)q * nrows + row0 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y[row0 + r] = t;
+    }
+}
+template <int TPR, int UNR>
+static void run_split(const char *name, int m, int n, int nwg, const int *ci_rm, const double *val_rm, const double *x, double *y, double nnz) {
+    // production slab tables for (m, nwg): rows_per_wg = ceil(m / nwg), W from the LDS budget with nslabs * rpw accumulators
+    const int rpw = (m + nwg - 1) / nwg;
+    int nslabs = 1, W = 0;
+    for (;; nslabs++) { const int budget = (160 * 1024 - 1024) / 8 - nslabs * rpw; W = (((n + nslabs - 1) / nslabs) + 63) & ~63; if (W <= budget) break; }
+    int *sp; int2 *seg; unsigned short *i16, *i16sm; double *vsm, *ypart; int *cnt;
+    CK(hipMalloc(&sp, (size_t)m * (nslabs + 1) * 4)); CK(hipMalloc(&seg, (size_t)m * nslabs * 8)); CK(hipMalloc(&i16, (size_t)nnz * 2)); CK(hipMalloc(&i16sm, ((size_t)nnz + 4) * 2)); CK(hipMalloc(&vsm, ((size_t)nnz + 4) * 8));
+    CK(hipMalloc(&ypart, (size_t)m * nslabs * 8)); CK(hipMalloc(&cnt, 4096)); CK(hipMemset(cnt, 0, 4096));
+    CK(hipMemset(i16sm, 0, ((size_t)nnz + 4) * 2)); CK(hipMemset(vsm, 0, ((size_t)nnz + 4) * 8));
+    hipLaunchKernelGGL(k_rebuild, dim3(4096), dim3(256), 0, 0, m, (int)(nnz / m), nslabs, W, ci_rm, i16, sp);
+    hipLaunchKernelGGL(k_slab_seg, dim3((m + rpw - 1) / rpw), dim3(1024), 0, 0, m, nslabs, rpw, (const int *)sp, seg);
+    hipLaunchKernelGGL(k_slab_permute, dim3(2048), dim3(256), 0, 0, m, nslabs, W, (const int *)sp, (const int2 *)seg, (const unsigned short *)i16, val_rm, vsm, i16sm);
+    CK(hipDeviceSynchronize());
+    const int nrb = ((m + rpw - 1) / rpw + nslabs - 1) / nslabs, grid = nrb * nslabs; const size_t lds = (size_t)(W + nslabs * rpw) * 8;
+    // reference with the production kernel on the same tables
+    std::vector<double> ref(m), got(m);
+    { const size_t lds0 = (size_t)(W + rpw) * 8;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slab_prod<TPR, UNR, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0));
+      hipLaunchKernelGGL((k_slab_prod<TPR, UNR, 1024>), dim3((m + rpw - 1) / rpw), dim3(1024), lds0, 0, m, n, nslabs, W, rpw, (const int2 *)seg, (const unsigned short *)i16sm, (const double *)vsm, x, y);
+      CK(hipMemcpy(ref.data(), y, (size_t)m * 8, hipMemcpyDeviceToHost)); }
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_slab_split<TPR, UNR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL((k_slab_split<TPR, UNR>), dim3(grid), dim3(1024), lds, 0, m, n, nslabs, W, rpw, (const int2 *)seg, (const unsigned short *)i16sm, (const double *)vsm, x, ypart, cnt, y);
+    CK(hipEventRecord(e0, 0));
+    for (int w = 0; w < 10; w++) hipLaunchKernelGGL((k_slab_split<TPR, UNR>), dim3(grid), dim3(1024), lds, 0, m, n, nslabs, W, rpw, (const int2 *)seg, (const unsigned short *)i16sm, (const double *)vsm, x, ypart, cnt, y);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+    CK(hipMemcpy(got.data(), y, (size_t)m * 8, hipMemcpyDeviceToHost));
+    double err = 0.0; for (int i = 0; i < m; i++) { double dd = fabs(got[i] - ref[i]); if (dd > err) err = dd; }
+    printf("%-44s wg %4d, W %5d, %2d slabs: %.3f ms  algorithmic %.2f TB/s  maxdiff vs production %.2e\n", name, grid, W, nslabs, ms, nnz * 12 / ms / 1e9, err); fflush(stdout);
+    CK(hipFree(sp)); CK(hipFree(seg)); CK(hipFree(i16)); CK(hipFree(i16sm)); CK(hipFree(vsm)); CK(hipFree(ypart)); CK(hipFree(cnt));
+}
 template <int TPR, int UNR>
 static void run_prod(const char *name, int m, int n, int nslabs, int W, int rpw, const int2 *seg, const unsigned short *i16, const double *v, const double *x, double *y, double nnz, const std::vector<double> &ref) {
     const int grid = (m + rpw - 1) / rpw; const size_t lds = (size_t)(W + rpw) * 8;
@@ -342,6 +456,7 @@ int main() {
     hipLaunchKernelGGL(k_gen, dim3(4096), dim3(256), 0, 0, m, n, per_row, W, nslabs, ci, ci16, val, sp);
     hipLaunchKernelGGL(k_fillx, dim3(256), dim3(256), 0, 0, n, x);
     CK(hipDeviceSynchronize());
+    if (getenv("LAB_FULL")) {
     std::vector<double> ref;
     run<0, 8>("V0 baseline tpr8", m, n, nslabs, W, rpw, sp, ci16, val, x, y, nnz, ref);
     run<2, 8>("V2 pred 8-way tpr8", m, n, nslabs, W, rpw, sp, ci16, val, x, y, nnz, ref);
@@ -376,6 +491,7 @@ int main() {
         CK(hipFree(segrm));
         CK(hipFree(vsm)); CK(hipFree(i16sm)); CK(hipFree(seg));
     }
+    }
     {   // compact-shaped product (k = 73000 active rows): workgroup geometry
         const int kk = 73000; const double nnzk = (double)kk * per_row;
         printf("compact shape k=%d\n", kk);
@@ -387,6 +503,18 @@ int main() {
         run_prod_wg<16, 8, 1024>("1024 thr, 512 wgs (2 waves of wgs)", kk, n, 512, 1, sp, nslabs, ci16, ci, val, x, y, nnzk);
         run_prod_wg<16, 8, 1024>("full m, production geometry", m, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnz);
         run_prod_wg<16, 8, 512>("full m, 512 thr 2 wg/CU", m, n, 512, 1, sp, nslabs, ci16, ci, val, x, y, nnz);
+        run_split<16, 8>("SPLIT k=73000, 256 old ranges", kk, n, 256, ci, val, x, y, nnzk);
+        run_split<16, 8>("SPLIT k=73000, 512 old ranges", kk, n, 512, ci, val, x, y, nnzk);
+        run_split<16, 8>("SPLIT k=73000, 252 old ranges", kk, n, 252, ci, val, x, y, nnzk);
+        run_split<16, 8>("SPLIT k=73000, 255 old ranges", kk, n, 255, ci, val, x, y, nnzk);
+        run_split<16, 8>("SPLIT k=73000, 250 old ranges", kk, n, 250, ci, val, x, y, nnzk);
+        run_split<16, 8>("SPLIT k=66000, 252 old ranges", 66000, n, 252, ci, val, x, y, 66000.0 * per_row);
+        run_split<16, 8>("SPLIT k=66000, 255 old ranges", 66000, n, 255, ci, val, x, y, 66000.0 * per_row);
+        run_split<16, 8>("SPLIT full m, 252 old ranges", m, n, 252, ci, val, x, y, nnz);
+        run_split<16, 8>("SPLIT k=66000, 256 old ranges", 66000, n, 256, ci, val, x, y, 66000.0 * per_row);
+        run_prod_wg<16, 8, 1024>("PROD  k=66000", 66000, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, 66000.0 * per_row);
+        run_split<16, 8>("SPLIT full m, 256 old ranges", m, n, 256, ci, val, x, y, nnz);
+        if (!getenv("LAB_FULL")) return 0;
     }
     // ---- slab-major storage: per workgroup, all row segments of slab 0, then of slab 1, ... (sequential stream per slab phase)
     {
