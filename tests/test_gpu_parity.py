@@ -586,3 +586,19 @@ def test_pcg_that_cannot_converge_is_an_error_not_a_silent_step(gpu_required, mo
     assert r["info"]["status_val"] == 1 and r["stats"]["pcg_soft_accepts"] == 0
     # (every solve ended by its stopping rule: relative 1e-12, or 1e-5 eps_abs in the unscaled inf-norm -- the latter may leave a
     # relative residual far above 1e-12 when the right-hand side of a late pass is itself of the order of 1e-6)
+
+
+def test_lost_producer_of_a_chained_solve_is_redone_stepwise_not_an_error(gpu_required, monkeypatch):
+    """round-1 advisor finding: a chained triangular solve that loses a producer ended the whole qpdo_solve with QPDO_ERROR.  Now the
+    iterate update of that pass is skipped on the device and the step is redone with the stepwise solves on a fresh factor; injected
+    at Newton pass 3, the solve must still reproduce the oracle -- counts, trace, iterates"""
+    monkeypatch.setenv("QPDO_LINSOLVE", "dense")
+    monkeypatch.setenv("QPDO_DENSE_CHAIN_INJECT", "3")
+    p = problems.random_qp(43, 1000, 700, 0.03, 50)
+    r = solver.solve_problem(p, verbose=0)
+    assert r["stats"]["chain_fallbacks"] == 1
+    o = ob.OracleSolver(p, ob.default_settings())
+    ro = o.solve()
+    assert_same_outcome(r, ro["info"], ro["x"], ro["y"], p)
+    assert_same_trace(r["trace"], o.trace())
+    o.close()
