@@ -35,9 +35,14 @@ CASES = {
     "schur_30k": (dict(rand=(123456 + 7, 30_000, 60_000, 0.01, 0)), dict()),
     # mid size with equality rows (tie hazard) just above the dense limit
     "pcg_13k_eq": (dict(rand=(123456 + 8, 13_000, 20_000, 0.01, 3000)), dict()),
+    # BASELINE configs[3] / the metric's configuration at FULL size (n=1e5, m=2e5), first passes only: the dense factor does not
+    # exist at this size (80 GB), so the oracle runs its Jacobi-PCG (tol 1e-12) -- ~0.5 s per CG iteration on 8 cores, hours for
+    # the whole solve -- and both sides stop at max_iter: the record pins the per-pass trace and the iterate after those passes
+    "C4_first16": (dict(cfg="C4", index=0), dict(max_iter=16)),
 }
+LINSOLVE = {"C4_first16": "pcg"}
 TRACE_FIELDS = ["kind", "n_active", "n_enter", "n_leave", "factor_branch", "tau", "res_prim", "res_dual",
-                "res_prim_in", "res_dual_in", "sigma", "eps_in"]
+                "res_prim_in", "res_dual_in", "sigma", "eps_in", "lin_iters", "t_end"]
 
 
 def make_problem(spec):
@@ -53,14 +58,15 @@ def main():
         spec, st = CASES[name]
         t0 = time.time()
         p = make_problem(spec)
-        o = ob.OracleSolver(p, ob.default_settings(**st))
+        o = ob.OracleSolver(p, ob.default_settings(**st), linsolve=LINSOLVE.get(name, "dense"), pcg_tol=1e-12, pcg_maxit=50000)
         r = o.solve()
         tr = o.trace()
         i = r["info"]
         meta = dict(spec=spec, settings=st, n=p["n"], m=p["m"],
                     info={k: i[k] for k in ("status_val", "iterations", "oterations", "newton_passes", "objective",
                                             "res_prim_norm", "res_dual_norm", "res_prim_in_norm", "res_dual_in_norm")},
-                    oracle_seconds=time.time() - t0, threads=os.cpu_count())
+                    oracle_seconds=time.time() - t0, threads=os.cpu_count(), oracle_linsolve=LINSOLVE.get(name, "dense"),
+                    oracle_lin_iters=i.get("lin_iters", 0))
         arrays = {f: np.array([t[f] for t in tr]) for f in TRACE_FIELDS}
         path = os.path.join(HERE, "big_%s.npz" % name)
         np.savez_compressed(path, meta=json.dumps(meta), x=r["x"], y=r["y"], **{"tr_" + k: v for k, v in arrays.items()})
