@@ -11,8 +11,10 @@ cases = []
 for f in ("big_pcg_13k_eq.npz", "big_schur_30k.npz"):
     z = np.load(os.path.join(gd, f)); meta = json.loads(str(z["meta"]))
     cases.append((f, golden_problem(meta["spec"]), meta, trace_from_npz(z), z["x"], z["y"]))
-for tol in (0, 1e-5, 1e-4, 1e-3):
-    os.environ["QPDO_PCG_ABS"] = "%g" % tol
+KNOB = os.environ.get("PROBE_KNOB", "QPDO_PCG_ABS")
+VALS = [float(v) for v in os.environ.get("PROBE_VALS", "0,1e-5,1e-4,1e-3").split(",")]
+for tol in VALS:
+    os.environ[KNOB] = "%g" % tol
     for f, p, meta, tr, x, y in cases:
         t0 = time.time(); r = solver.solve_problem(p, verbose=0); dt = time.time() - t0
         oi = meta["info"]
@@ -21,8 +23,8 @@ for tol in (0, 1e-5, 1e-4, 1e-3):
             tol, f, dt, r["info"]["iterations"], oi["iterations"], same, same_trace_counts(r["trace"], tr), r["stats"]["lin_iters"],
             np.abs(r["x"] - x).max() / max(1, np.abs(x).max()), np.abs(r["y"] - y).max() / max(1, np.abs(y).max())), flush=True)
 p = problems.config_qp("C4")
-for tol in (0, 1e-5, 1e-4):
-    os.environ["QPDO_PCG_ABS"] = "%g" % tol
+for tol in VALS:
+    os.environ[KNOB] = "%g" % tol
     s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0)
     t0 = time.time(); r = s.solve(); dt = time.time() - t0
     rp, rd = problems.kkt_residuals(p, r["x"], r["y"])
