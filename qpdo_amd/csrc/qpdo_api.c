@@ -880,7 +880,10 @@ long qpdo_amd_solve_batch(long count, QPDOAmdBatchItem *items, const QPDOSetting
             int ndev = qdev_device_count();
             if (ndev > 0) {
                 int device = env_int("QPDO_DEVICE", env_int("LOCAL_RANK", 0)) % ndev;
-                if (qdev_small_batch(device, count, items, settings) == 0) return 0;
+                const double tb0 = wall_now();
+                const int rcb = qdev_small_batch(device, count, items, settings);
+                if (env_int("QPDO_SMALL_PROF", 0) == 2) fprintf(stderr, "[qpdo_small host] qdev_small_batch total   %.3f s\n", wall_now() - tb0);
+                if (rcb == 0) return 0;
                 QPDO_EPRINT("fused batch kernel failed (%s); using the generic path", qdev_small_last_error());
             }
         }
