@@ -330,8 +330,13 @@ def main():
     elif s.stats()["linsolve"] == 1:
         # dense LDL' (C2): the dominant kernel is the fp64-MFMA trailing update; MFMA utilisation comes from the committed
         # PMC profile, the live figure here is the factor's flop rate from the solve's own statistics
-        roof = dict(bound="mfma", kernel="k_ldl_syrk (fp64 MFMA trailing update of the dense LDL')", achieved=None, peak=78.6, unit="TFLOP/s",
-                    frac=None, traffic=None, factor_count=s.stats()["factor_count"])
+        fc = s.stats()["factor_count"]
+        t_f, chk = s.bench_dense_factor(reps=5)           # HIP events on the solver's stream, the factor of the final pass's weights
+        tf = cfg["n"] ** 3 / 3.0 / t_f / 1e12
+        roof = dict(bound="mfma", kernel="dense LDL' factorization (k_ldl_syrk fp64 MFMA trailing update + diag / panel chain)", achieved=tf, peak=78.6,
+                    unit="TFLOP/s", frac=tf / 78.6, traffic=None, factor_seconds=t_f, flops_per_factor=cfg["n"] ** 3 / 3.0, factor_count=fc,
+                    solve_residual_check=chk, note="n^3/3 flops over the HIP-event time of one factorization; MFMA-busy share of k_ldl_syrk in "
+                                                   "profiles/r01_c2_dense_mfma_util.json (35.5 % of 1024 SIMDs)")
     elif ac_n > at_n and ac_time > 0:
         bench_t, full_bytes = s.bench_spmv(0, reps=20)
         achieved = ac_bytes / ac_time / 1e9

@@ -129,3 +129,24 @@ def test_schur_mode_mid_size_instances_match_oracle(i, gpu_required, monkeypatch
     assert same_trace_counts(r["trace"], to)
     assert r["stats"]["schur_passes"] > 0
     assert close_vec(r["x"], ox, 1e-7) and close_vec(r["y"], oy, 1e-7)
+
+
+@pytest.mark.parametrize("qdiag", [0.0, 1e-3])
+def test_schur_mode_on_mid_size_lp_like_instances(qdiag, gpu_required, monkeypatch):
+    """Q = 0 (an LP) and a weak diagonal Q at a size where the Schur-complement mode takes over: Dq is then only the proximal sigma
+    (1e-3 down to 1e-7), so the inner system A_c A_c' / sigma + D^-1 and the absolute stopping rule work at their extremes"""
+    import scipy.sparse as sp
+    monkeypatch.setenv("QPDO_LINSOLVE", "pcg")
+    monkeypatch.setenv("QPDO_PCG_SCHUR", "1")
+    p = problems.random_qp(8101, 700, 1500, 0.03)
+    p["Q"] = sp.diags(np.full(700, qdiag)).tocsc() if qdiag > 0 else sp.csc_matrix((700, 700))
+    o = ob.OracleSolver(p, ob.default_settings(max_iter=600))
+    ro = o.solve()
+    oi, ox, oy, to = dict(ro["info"]), np.array(ro["x"]), np.array(ro["y"]), o.trace()
+    o.close()
+    r = solver.solve_problem(p, verbose=0, max_iter=600)
+    gi = r["info"]
+    assert (gi["status_val"], gi["iterations"], gi["oterations"]) == (oi["status_val"], oi["iterations"], oi["oterations"])
+    assert same_trace_counts(r["trace"], to)
+    if oi["status_val"] == 1:
+        assert close_vec(r["x"], ox, 1e-7) and close_vec(r["y"], oy, 1e-7)
