@@ -431,8 +431,12 @@ def main():
             t0 = time.time(); s3 = solver.QPDO().setup(p2["Q"], p2["q"], p2["A"], p2["l"], p2["u"], Qstype=-1, verbose=0); ts = time.time() - t0
             s3.solve()                                                            # warm-up (code objects, allocations)
             t0 = time.time(); r3 = s3.solve(); L.qpdo_amd_sync(s3._w); dt3 = time.time() - t0
-            st3 = s3.stats(); s3.delete()
+            st3 = s3.stats()
+            t_f3, _ = s3.bench_dense_factor(reps=5) if st3["linsolve"] == 1 else (None, None)
+            s3.delete()
             out["other_configs"] = {"C2": dict(workload="n=10000, m=20000, density 0.01, cold start, default settings", time_to_eps_s=dt3, setup_s=ts,
+                                               roofline=(dict(bound="mfma", kernel="dense LDL' factorization", achieved=1e4 ** 3 / 3 / t_f3 / 1e12, peak=78.6, unit="TFLOP/s",
+                                                              frac=1e4 ** 3 / 3 / t_f3 / 1e12 / 78.6, factor_seconds=t_f3) if t_f3 else None),
                                                newton_iters_per_s=st3["newton_passes"] / dt3, status_val=r3["info"]["status_val"],
                                                iterations=r3["info"]["iterations"], linsolve="dense-ldlt" if st3["linsolve"] == 1 else "pcg",
                                                factor_count=st3["factor_count"], lowrank_solves=st3["lowrank_solves"])}
