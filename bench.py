@@ -264,6 +264,16 @@ def main():
     cfg = problems.CONFIGS[a.workload]
     t0 = time.time()
     rows_mode = (a.partition == "rows")
+    # Independent QPs on N GPUs: instance j has seed offset j.  A cold solve of C4 takes 50-71 passes depending on the seed, so with
+    # ONE instance per rank the slowest seed would set the wall time of every step.  Each rank therefore keeps K = min(N, 4) workspaces
+    # (seeds rank, rank+1, .. mod N; 20 GB of HBM each at C4) and step s solves workspace s mod K: the same unit of work per step, a
+    # balanced sum over the timed steps, still no collective and no host traffic inside the timed region.  N = 1: seed 0 only.
+    K = 1
+    if not rows_mode:
+        if os.environ.get("QPDO_BENCH_ROTATE"):
+            K = max(1, int(os.environ["QPDO_BENCH_ROTATE"]))      # (tests of the rotation on one GPU; 1 switches it off)
+        elif world > 1:
+            K = min(world, 4)
     prob = problems.config_qp(a.workload, index=0 if rows_mode else rank)
     t_gen = time.time() - t0
     if rows_mode:      # every rank holds the same instance; the library keeps its row slice on the GPU
@@ -280,10 +290,15 @@ def main():
     s = solver.QPDO().setup(prob["Q"], prob["q"], prob["A"], prob["l"], prob["u"], Qstype=-1, **st)
     t_setup = time.time() - t0
     L = solver.lib()
+    ws = [(prob, s)]
+    for j in range(1, K):
+        pj = problems.config_qp(a.workload, index=(rank + j) % max(world, K))
+        ws.append((pj, solver.QPDO().setup(pj["Q"], pj["q"], pj["A"], pj["l"], pj["u"], Qstype=-1, **st)))
 
-    for _ in range(a.warmup):
-        s.solve()
-    L.qpdo_amd_sync(s._w)
+    for i in range(a.warmup):
+        ws[i % K][1].solve()
+    for _, sj in ws:
+        L.qpdo_amd_sync(sj._w)
     barrier(dist)
     t0 = time.time()
     newton = cg = 0
@@ -292,24 +307,30 @@ def main():
     at_time = at_n = 0.0
     ac_time = ac_bytes = ac_n = 0.0
     schur_passes = 0
-    for _ in range(a.steps):
-        r = s.solve()
-        stt = s.stats()
+    for i in range(a.steps):
+        prob_i, s_i = ws[i % K]
+        r = s_i.solve()
+        stt = s_i.stats()
         newton += stt["newton_passes"]; cg += stt["lin_iters"]
         iters += r["info"]["iterations"]; oters += r["info"]["oterations"]
         statuses.append(r["info"]["status_val"])
         at_time += stt["spmv_Q_avg_s"] * stt["spmv_Q_samples"]; at_n += stt["spmv_Q_samples"]
         ac_time += stt["spmv_Ac_time_s"]; ac_bytes += stt["spmv_Ac_bytes"]; ac_n += stt["spmv_Ac_samples"]; schur_passes += stt["schur_passes"]
-    L.qpdo_amd_sync(s._w)
+    for _, sj in ws:
+        L.qpdo_amd_sync(sj._w)
     barrier(dist)
     dt = time.time() - t0
+    prob_last = ws[(a.steps - 1) % K][0] if a.steps > 0 else prob
+    for _, sj in ws[1:]:
+        sj.delete()
+
     dt_max = allreduce(dist, [dt], "max")[0]
     tot_newton, tot_cg = allreduce(dist, [newton, cg], "sum")
     if rows_mode:      # one QP: every rank counted the same passes
         tot_newton, tot_cg = tot_newton / world, tot_cg / world
 
     last = r
-    rp, rd = problems.kkt_residuals(prob, last["x"], last["y"]) if last["info"]["status_val"] not in (-3, -4) else (None, None)
+    rp, rd = problems.kkt_residuals(prob_last, last["x"], last["y"]) if last["info"]["status_val"] not in (-3, -4) else (None, None)
     # roofline of the dominant kernel, live HIP-event samples from the timed solves.  With the Schur-complement mode
     # of the PCG the bulk of the time is the inner solves' A_c product (k_spmv_slab<EpiSchurW>: the k active rows of A,
     # compact index space, k changes per pass, so bytes and time are summed over the samples); otherwise it is the Q
@@ -388,7 +409,8 @@ def main():
                                        (", max_time=%gs" % a.max_time) if a.max_time > 0 else ""),
                        "n": cfg["n"], "m": cfg["m"], "density": cfg["density"], "linsolve": ("pcg: Jacobi + heavy-row deflation, Schur-complement mode on %d of %d Newton passes" % (schur_passes, newton)) if s.stats()["linsolve"] == 0 else "dense-ldlt",
                        "parallelism": ("one QP, rows of A partitioned over the GPUs, RCCL all-reduce of A'y" if rows_mode
-                                       else "independent QPs per GPU, no collective")},
+                                       else "independent QPs per GPU, no collective" + ("; each rank cycles through %d seeded instances, one cold solve per step" % K if K > 1 else "")),
+                       "instances_per_rank": K},
             # time-to-eps: the solve alone (inputs resident in HBM), and with qpdo_setup added -- the reference's info->run_time
             # covers setup + solve (src/qpdo.c:461-464)
             "time_to_eps_s": dt_max / max(1, a.steps) if all_solved else None,
