@@ -86,3 +86,24 @@ print(json.dumps(dict(counts=[r["info"][k] == ro["info"][k] for k in ("status_va
     assert st["linsolve"] == 0 and st["schur_passes"] > 0 and st["collectives"] > 0
     assert st["inner_collectives"] == st["inner_steps"] + st["inner_solves"]
     assert r["second"] == "refused"
+
+
+@pytest.mark.parametrize("workload,extra", [("C2", ["--steps", "3", "--warmup", "1", "--no-cpu-baseline"]),
+                                            ("C3", ["--steps", "2", "--warmup", "1", "--max-iter", "300", "--batch-count", "512", "--no-cpu-baseline"])])
+def test_bench_contract_with_two_ranks_on_one_gpu(workload, extra, gpu_required):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU; here both ranks land on the one GPU):
+    one JSON line from rank 0 with the whole-job aggregate; C2: independent QPs, each rank cycling through two seeded instances;
+    C3: the batch sharded over the ranks"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613" if workload == "C2" else "29614", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["unit"] == "newton_iters/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    if workload == "C2":
+        assert d["scaling"] == "weak" and d["config"]["instances_per_rank"] == 2 and all(v == 1 for v in d["status_val"])
+        assert d["newton_passes"] > 2 * 3 * 30               # both ranks' passes are in the aggregate
+    else:
+        assert d["scaling"] == "strong" and d["items"] == 2 * 512 and d["failed"] == 0
