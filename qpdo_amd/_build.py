@@ -62,8 +62,10 @@ def build_lib(force=False, verbose=False):
     common = ["-O3", "-fPIC", "-I", INCLUDE, "-I", CSRC]
     for s in HIP_SOURCES:
         o = os.path.join(CSRC, s + ".o")
+        # -amdgpu-mfma-vgpr-form: accumulators of the fp64 MFMA loops stay in VGPRs; the default heuristics put them in AGPRs inside
+        # the loop and in VGPRs across its back edge (64 v_accvgpr moves and a drained matrix pipeline per 16 MFMAs in k_ldl_syrk)
         cmd = [cc, "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
-               *common, "-c", os.path.join(CSRC, s), "-o", o]
+               "-mllvm", "-amdgpu-mfma-vgpr-form", *common, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         subprocess.check_call(cmd)

@@ -3,7 +3,7 @@
 N=${1:-10000}
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/dl && rocprofv3 --kernel-trace --output-format csv -d /tmp/dl -o d -- python3 $GRAFT_REPO_ROOT/tools/dense_lab.py $N 3 > /dev/null 2>&1
 F=$(find /tmp/dl -name "*kernel_trace.csv" | head -1)
-python3 - <<PY
+cp "$F" $GRAFT_REPO_ROOT/gpurun_out/last_dense_trace.csv 2>/dev/null; python3 - <<PY
 import csv, collections
 rows=list(csv.DictReader(open("$F")))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
