@@ -8,7 +8,7 @@
  * Environment variables read once per qpdo_setup:
  *   QPDO_DEVICE      HIP device ordinal (default: LOCAL_RANK if set, else 0)
  *   QPDO_LINSOLVE    "pcg" | "dense" | "auto" (default auto: dense LDL' for n <= QPDO_DENSE_MAX_N = 12288)
- *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change instead of the low-rank update of the kept dense factor
+ *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change, "1": low-rank update of the kept dense factor (default: from n = 2560 up)
  *   QPDO_DENSE_LOOKAHEAD "0": factor on one stream (no overlap of the next panel with the trailing update)
  *   QPDO_DENSE_RESERVE_CUS  CUs left out of the trailing-update stream's mask (default 32; 0 = no mask)
  *   QPDO_DENSE_SOLVE "steps": per-block-step triangular solve kernels instead of the one-launch chained solves
