@@ -9,7 +9,7 @@
  *   QPDO_DEVICE      HIP device ordinal (default: LOCAL_RANK if set, else 0)
  *   QPDO_LINSOLVE    "pcg" | "dense" | "auto" (default auto: dense LDL' for n <= QPDO_DENSE_MAX_N = 12288)
  *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change, "1": low-rank update of the kept dense factor (default: from n = 2560 up)
- *   QPDO_DENSE_LOOKAHEAD "0": factor on one stream (no overlap of the next panel with the trailing update)
+ *   QPDO_DENSE_LOOKAHEAD "0": factor on one stream, "1": overlap the next panel with the trailing update (default: from n = 7000 up)
  *   QPDO_DENSE_RESERVE_CUS  CUs left out of the trailing-update stream's mask (default 32; 0 = no mask)
  *   QPDO_DENSE_SOLVE "steps": per-block-step triangular solve kernels instead of the one-launch chained solves
  *   QPDO_SETUP_THREADS  host threads of the CSC -> CSR conversions in qpdo_setup (default min(16, cores)); QPDO_SETUP_PROF=1 prints phase times

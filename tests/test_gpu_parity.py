@@ -215,6 +215,29 @@ def test_dense_factor_is_reused_when_weights_do_not_change(gpu_required, monkeyp
     assert r["stats"]["factor_count"] >= 1 and r["stats"]["lin_iters"] == 0
 
 
+def test_dense_factor_schedules_leave_the_same_bits(gpu_required, monkeypatch):
+    """look-ahead on a second stream, the XCD-aware tile order, the k-chunk depth and the one-launch outer panel only reschedule
+    the factorization: every element of K receives the same updates in the same order, so the solve is bit-identical"""
+    monkeypatch.setenv("QPDO_LINSOLVE", "dense")
+    monkeypatch.setenv("QPDO_DENSE_LOWRANK", "0")
+    p = problems.random_qp(77, 1500, 2600, 0.01, 100)
+    base = None
+    for var in ({"QPDO_DENSE_LOOKAHEAD": "0"}, {"QPDO_DENSE_LOOKAHEAD": "1"}, {"QPDO_DENSE_LOOKAHEAD": "1", "QPDO_SYRK_SWZ": "0"},
+                {"QPDO_DENSE_LOOKAHEAD": "1", "QPDO_SYRK_KC": "32"}, {"QPDO_DENSE_LOOKAHEAD": "1", "QPDO_DENSE_FPANEL": "1"},
+                {"QPDO_DENSE_LOOKAHEAD": "0", "QPDO_DENSE_FPANEL": "1"}):
+        for k in ("QPDO_DENSE_LOOKAHEAD", "QPDO_SYRK_SWZ", "QPDO_SYRK_KC", "QPDO_DENSE_FPANEL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in var.items():
+            monkeypatch.setenv(k, v)
+        r = solver.solve_problem(p, verbose=0)
+        assert r["info"]["status_val"] == 1 and r["stats"]["chain_fallbacks"] == 0, var
+        if base is None:
+            base = r
+        else:
+            assert r["info"]["iterations"] == base["info"]["iterations"], var
+            assert np.array_equal(r["x"], base["x"]) and np.array_equal(r["y"], base["y"]), var
+
+
 def test_dense_lowrank_update_matches_refactoring(gpu_required, monkeypatch):
     """few rows entering/leaving: the kept factor is updated instead of rebuilt (reference
     src/cholmod_interface.c:57-93, src/newton.c:21-30); the solve must be indistinguishable from refactoring"""
