@@ -86,6 +86,28 @@ def test_random_instances_match_live_oracle(seed, n, m, dens, neq, st, linsolve,
     o.close()
 
 
+@pytest.mark.parametrize("seed,n,m,dens,neq", [
+    (61, 2400, 4800, 0.01, 0),        # dense, below the low-rank threshold (n < 2560): every weight change refactors, one stream
+    (62, 3000, 6000, 0.01, 300),      # dense, low-rank updates of the kept factor, one stream
+    (63, 7300, 12000, 0.005, 0),      # dense, low-rank updates + look-ahead on the second stream (n >= 7000)
+])
+def test_default_dense_regimes_match_live_oracle(seed, n, m, dens, neq, gpu_required, monkeypatch):
+    """the DEFAULT solver selection on both sides of its size thresholds (low-rank updates from n = 2560, look-ahead from n = 7000; C2
+    and the PCG sizes are covered by the committed fixtures) against the oracle run here: counts, per-pass trace, iterates"""
+    for k in list(os.environ):
+        if k.startswith("QPDO_"):
+            monkeypatch.delenv(k)
+    p = problems.random_qp(seed, n, m, dens, neq)
+    o = ob.OracleSolver(p, ob.default_settings())
+    ro = o.solve()
+    r = solver.solve_problem(p, verbose=0)
+    assert r["stats"]["linsolve"] == 1 and r["stats"]["lin_iters"] == 0
+    assert (r["stats"]["lowrank_solves"] > 0) == (n >= 2560)
+    assert_same_outcome(r, ro["info"], ro["x"], ro["y"], p)
+    assert_same_trace(r["trace"], o.trace())
+    o.close()
+
+
 def test_scaling_is_bit_exact(gpu_required):
     """Ruiz + cost scaling (reference src/scaling.c:24-91) is elementwise: identical bits expected"""
     p = problems.config_qp("C1")
