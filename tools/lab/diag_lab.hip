@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 #include <cmath>
+#include <cstring>
 int main() {
     const int ld = 64;
     std::vector<double> A(64 * 64);
@@ -32,6 +33,10 @@ int main() {
         err = fmax(err, fabs(s - A[i + j * 64]));
     }
     printf("max |L D L' - A| = %.3e\n", err);
+    { std::vector<double> Lv(64 * 64), Iv(64 * 64); (void)hipMemcpy(Iv.data(), Li, 64 * 64 * 8, hipMemcpyDeviceToHost);
+      unsigned long long h = 1469598103934665603ull; auto mix = [&](const double *p, int n) { for (int i = 0; i < n; i++) { unsigned long long b; memcpy(&b, p + i, 8); h = (h ^ b) * 1099511628211ull; } };
+      for (int i = 0; i < 64; i++) for (int j = 0; j < i; j++) mix(&L[i + j * 64], 1);
+      mix(D.data(), 64); mix(Iv.data(), 64 * 64); printf("hash of L, D, L^-1: %016llx\n", h); }
     (void)hipEventRecord(e0);
     for (int rep = 0; rep < 200; rep++) hipLaunchKernelGGL(k_ldl_diag_blocked, dim3(1), dim3(256), 0, 0, K, ld, 0, Dg, Li, LiT);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
