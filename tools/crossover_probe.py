@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qpdo_amd import problems, solver
-for n in (1000, 2000, 4000, 6000, 8000, 10000, 12000, 14000, 16000):
+for n in ([int(a) for a in sys.argv[1:]] or [1000, 2000, 4000, 6000, 8000, 10000, 12000, 14000, 16000]):
     p = problems.random_qp(500 + n, n, 2 * n, 0.01, 0)
     out = []
     for mode in ("dense", "pcg"):
