@@ -30,6 +30,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# N ranks on one node share its host cores: the OpenMP conversions of qpdo_setup and the generator take 1/N of them each (set before
+# libgomp loads; untimed either way, but N x all cores oversubscribes the node while every rank sets up at once).
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "OMP_NUM_THREADS" not in os.environ:
+    try:
+        _aff = len(os.sched_getaffinity(0))
+    except Exception:
+        _aff = os.cpu_count() or 1
+    os.environ["OMP_NUM_THREADS"] = str(max(1, _aff // int(os.environ["WORLD_SIZE"])))
+
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
 C3_COUNT = 4096           # BASELINE.json configs[2]
 
