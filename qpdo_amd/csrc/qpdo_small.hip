@@ -199,61 +199,88 @@ __device__ void small_assemble(SmallQP &P, const KView &kv, const double *dw, do
 // so the inner loop walks the row with an incremental 32-bit offset.  Separate instantiations keep the LDS
 // pointer provenance visible to the compiler (ds_read instead of flat loads).
 template <bool PACKED>
-__device__ __forceinline__ void small_factor_t(int n, double *__restrict__ K, double *__restrict__ lcol, double *__restrict__ tcol) {
+__device__ __forceinline__ void small_factor_t(int n, double *__restrict__ K, double *__restrict__ lcol, double *__restrict__ tcol,
+                                               double *__restrict__ lcol1, double *__restrict__ tcol1) {
     // Right-looking (outer-product) LDL'.  Element (i,j) receives  -= l_ik * (l_jk d_k)  at step k, i.e. the same
     // subtractions in the same ascending-k order as the left-looking reference loop - bit-identical results - but
     // every step updates the whole trailing triangle, so all waves of the workgroup have work.
     // (The reference skips k when l_jk == 0; subtracting x * 0 leaves an element unchanged bit for bit.)
+    // TWO columns per barrier pair: the kernel is bound by the latency of its barrier-separated steps, not by arithmetic.  Every
+    // thread applies step k to its entry of column k+1 itself -- the subtraction the trailing update would have made, with
+    // l_{k+1,k} and d_{k+1} recomputed by every thread from the same LDS values, so the same bits -- and the trailing update then
+    // makes the subtractions of step k and of step k+1 one after the other.
     const int li = threadIdx.x & 63, wj = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int offk = 0;                                   // off(k)
-    for (int k = 0; k < n; k++) {
+    int k = 0;
+    for (; k + 1 < n; k += 2) {
+        const int offk1 = offk + (PACKED ? n - k - 1 : n);            // off(k+1)
         const double dk = K[offk + k], inv = 1.0 / dk;
-        for (int i = k + 1 + (int)threadIdx.x; i < n; i += blockDim.x) {
-            const double l = K[offk + i] * inv;
-            K[offk + i] = l; lcol[i] = l; tcol[i] = l * dk;
+        const double lk1 = K[offk + k + 1] * inv;                     // l_{k+1,k}
+        const double tk1 = lk1 * dk;                                  // its product with d_k: tcol[k+1] of step k
+        const double dk1 = K[offk1 + k + 1] - lk1 * tk1;              // K(k+1,k+1) after step k = d_{k+1}
+        const double inv1 = 1.0 / dk1;
+        // (K(k+1,k) and K(k+1,k+1) are inputs of every thread above: they are overwritten after the barrier, by one thread)
+        for (int i = k + 2 + (int)threadIdx.x; i < n; i += blockDim.x) {
+            const double l0 = K[offk + i] * inv;
+            K[offk + i] = l0; lcol[i] = l0; tcol[i] = l0 * dk;
+            const double v1 = K[offk1 + i] - l0 * tk1;                // column k+1 after step k
+            const double l1 = v1 * inv1;
+            K[offk1 + i] = l1; lcol1[i] = l1; tcol1[i] = l1 * dk1;
         }
         SYNC;
+        if (threadIdx.x == 0) { K[offk + k + 1] = lk1; K[offk1 + k + 1] = dk1; }
         // four columns of the trailing triangle per trip: the LDS reads of all four are issued before the first
-        // dependent multiply (each element still receives exactly  K(i,j) -= l_ik * (l_jk d_k):  same bits)
-        for (int j0 = k + 1 + wj; j0 < n; j0 += 4 * nw) {
-            int jj[4], off[4]; double tj[4];
+        // dependent multiply (each element still receives exactly  K(i,j) -= l_ik * (l_jk d_k), k then k+1:  same bits)
+        for (int j0 = k + 2 + wj; j0 < n; j0 += 4 * nw) {
+            int jj[4], off[4]; double tj0[4], tj1[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 jj[u] = j0 + u * nw;
                 const int jc = jj[u] < n ? jj[u] : n - 1;
-                tj[u] = tcol[jc];
+                tj0[u] = tcol[jc]; tj1[u] = tcol1[jc];
                 off[u] = PACKED ? jc * n - (jc * (jc + 1)) / 2 : jc * n;
             }
-            for (int i = k + 1 + li; i < n; i += 64) {
-                const double a = lcol[i];
+            for (int i = k + 2 + li; i < n; i += 64) {
+                const double a0 = lcol[i], a1 = lcol1[i];
                 double v[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) v[u] = (jj[u] < n && i >= jj[u]) ? K[off[u] + i] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 4; u++) if (jj[u] < n && i >= jj[u]) K[off[u] + i] = v[u] - a * tj[u];
+                for (int u = 0; u < 4; u++) if (jj[u] < n && i >= jj[u]) { const double w = v[u] - a0 * tj0[u]; K[off[u] + i] = w - a1 * tj1[u]; }
             }
         }
         SYNC;
-        offk += PACKED ? n - k - 1 : n;
+        offk = offk1 + (PACKED ? n - k - 2 : n);
+    }
+    if (k < n) {                                    // odd n: the last column has nothing below it
+        SYNC;
     }
 }
-// x lives in LDS (xs) for the duration of the solve
+// x lives in LDS (xs) for the duration of the solve.  Two columns per barrier, as in the factorization: every thread applies step j
+// to entry j+1 itself (x_{j+1} = xs[j+1] - L(j+1,j) x_j, the subtraction the column sweep would have made), then each entry receives
+// the subtractions of column j and of column j+1 in that order -- the operations of the one-column loop, so the same bits.
 __device__ void small_ldl_solve(SmallQP &P, const KView &kv, const double *b, double *xout, double *xs) {
     const int n = P.n;
     FOR_T(i, n) xs[i] = b[i];
     SYNC;
-    for (int j = 0; j < n; j++) {                 // L z = b  (x_j is final when the loop reaches it)
+    for (int j = 0; j + 1 < n; j += 2) {          // L z = b  (x_j is final when the loop reaches it)
         const double xj = xs[j];
-        FOR_T(ii, n - j - 1) { const int i = j + 1 + ii; xs[i] -= kv.at(i, j) * xj; }
+        const double xj1 = xs[j + 1] - kv.at(j + 1, j) * xj;
+        FOR_T(ii, n - j - 2) { const int i = j + 2 + ii; const double t = xs[i] - kv.at(i, j) * xj; xs[i] = t - kv.at(i, j + 1) * xj1; }
         SYNC;
+        if (threadIdx.x == 0) xs[j + 1] = xj1;    // (an input of every thread above; read again only after the barrier below the loop)
     }
+    SYNC;
     FOR_T(j, n) xs[j] /= kv.at(j, j);
     SYNC;
-    for (int j = n - 1; j >= 0; j--) {            // L' x = z, column oriented: x_j is final, eliminate it from the rows above
+    for (int j = n - 1; j >= 1; j -= 2) {         // L' x = z, column oriented: x_j is final, eliminate it from the rows above
         const double xj = xs[j];
-        FOR_T(i, j) xs[i] -= kv.at(j, i) * xj;
+        const double xj1 = xs[j - 1] - kv.at(j, j - 1) * xj;
+        FOR_T(i, j - 1) { const double t = xs[i] - kv.at(j, i) * xj; xs[i] = t - kv.at(j - 1, i) * xj1; }
         SYNC;
+        if (threadIdx.x == 0) xs[j - 1] = xj1;
     }
+    SYNC;
     FOR_T(i, n) xout[i] = xs[i];
     SYNC;
 }
@@ -608,7 +635,7 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
             FOR_T(j, n) rhs[j] = -res_dual_in[j] - Atdy[j];
             SYNC;
             PH(PH_PREP);
-            if (!factor_valid) { small_assemble(P, kv, dw, sigma_f, rp_s, d_s); PH(PH_ASM); if (klds_ok) small_factor_t<true>(n, Klds, colbuf, tk); else small_factor_t<false>(n, P.K, colbuf, tk); PH(PH_FACTOR); factor_valid = 1; nfactor++; }
+            if (!factor_valid) { small_assemble(P, kv, dw, sigma_f, rp_s, d_s); PH(PH_ASM); if (klds_ok) small_factor_t<true>(n, Klds, colbuf, tk, xs, tk + n); else small_factor_t<false>(n, P.K, colbuf, tk, xs, tk + n); PH(PH_FACTOR); factor_valid = 1; nfactor++; }
             last_branch = branch; last_sigma_f = sigma_f;
             small_ldl_solve(P, kv, rhs, dx, xs);
             PH(PH_SOLVE);
