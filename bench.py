@@ -242,11 +242,12 @@ def run_batch(a, rank, world, dist):
 def small_kernel_roofline(newton_passes, seconds, n_gpus):
     """seconds: HIP-event duration of the kernel launch.  What bounds k_small_solve: not HBM (the problem data once, ~70 KB per QP) and not LDS bandwidth
     (a few % of the aggregate), but the LATENCY of dependent, barrier-separated steps: a Newton pass walks about
-    m + 4n + 55 of them (assembly row by row, two per factor column, the two triangular solves, the bitonic sort stages);
+    m + 2n + 55 of them (assembly row by row, one per factor column and one per column of the two triangular solves -- two columns
+    share a barrier pair --, the bitonic sort stages);
     bit-identity with the oracle fixes the operation order that makes them dependent.  achieved = ns per step of one
     workgroup (two interleaved per CU), floor = barrier + LDS round trip + a dozen dependent operations."""
     n, m = 120, 360
-    steps = m + 4 * n + 55
+    steps = m + 2 * n + 55
     wgs = 512 * max(1, n_gpus)                     # workgroups in flight: 2 per CU x 256 CUs per GPU
     ns_per_step = seconds * wgs / max(1.0, newton_passes) / steps * 1e9
     floor = 250.0
