@@ -40,8 +40,9 @@ CASES = {
     # the whole solve -- and both sides stop at max_iter: the record pins the per-pass trace and the iterate after those passes
     "C4_first16": (dict(cfg="C4", index=0), dict(max_iter=16)),
     "C4_first32": (dict(cfg="C4", index=0), dict(max_iter=32)),
+    "C4_first40": (dict(cfg="C4", index=0), dict(max_iter=40)),
 }
-LINSOLVE = {"C4_first16": "pcg", "C4_first32": "pcg"}
+LINSOLVE = {"C4_first16": "pcg", "C4_first32": "pcg", "C4_first40": "pcg"}
 TRACE_FIELDS = ["kind", "n_active", "n_enter", "n_leave", "factor_branch", "tau", "res_prim", "res_dual",
                 "res_prim_in", "res_dual_in", "sigma", "eps_in", "lin_iters", "t_end"]
 
