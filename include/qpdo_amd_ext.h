@@ -12,9 +12,9 @@
  *   QPDO_DENSE_LOOKAHEAD "0": factor on one stream, "1": overlap the next panel with the trailing update (default: from n = 7000 up)
  *   QPDO_DENSE_RESERVE_CUS  CUs left out of the trailing-update stream's mask (default 32; 0 = no mask)
  *   QPDO_DENSE_SOLVE "steps": per-block-step triangular solve kernels instead of the one-launch chained solves
- *   Experiment knobs of the dense factor, read per factorization (every setting leaves the same factor bits except QPDO_DENSE_DIAG):
+ *   Experiment knobs of the dense factor (every setting leaves the same factor bits):
  *   QPDO_DENSE_OUTER (block columns per outer panel, default 4), QPDO_SYRK_KC (16 | 32), QPDO_SYRK_SWZ ("0": 2-D tile grid instead of
- *   the XCD-aware order), QPDO_DENSE_DIAG ("0": the two-wave diagonal-block kernel), QPDO_DENSE_FPANEL ("1": a whole outer panel in one
+ *   the XCD-aware order), QPDO_DENSE_FPANEL ("1": a whole outer panel in one
  *   launch; slower at present)
  *   QPDO_SETUP_THREADS  host threads of the CSC -> CSR conversions in qpdo_setup (default min(16, cores)); QPDO_SETUP_PROF=1 prints phase times
  *   QPDO_SLAB_TPR    lanes per row segment of the slab SpMV (8 | 16 | 32, default 16)
