@@ -80,6 +80,10 @@ def lib():
         L.oracle_vec_prod.argtypes = [dp, dp, C.c_int64]
         L.oracle_pwa_linesearch.restype = C.c_double
         L.oracle_pwa_linesearch.argtypes = [C.c_int64, C.c_double, C.c_double, dp, dp]
+        L.oracle_K_apply.argtypes = [C.c_void_p, dp, dp, C.c_int]
+        L.oracle_set_factor_state.argtypes = [C.c_void_p, C.c_double, dp]
+        L.oracle_compact_ok.restype = C.c_int
+        L.oracle_compact_ok.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -167,6 +171,18 @@ class OracleSolver:
 
     def set_fix_status_reset(self, on):
         lib().oracle_set_fix_status_reset(self.h, int(on))
+
+    def K_apply(self, v, sigma_f, d, compact):
+        """K v = Q v + sigma_f v + A' (d o (A v)) through the PCG operator (compact=1: the 32-bit compact copies)"""
+        v = np.ascontiguousarray(v, np.float64)
+        d = np.ascontiguousarray(d, np.float64)
+        out = np.zeros(self.n)
+        lib().oracle_set_factor_state(self.h, float(sigma_f), _dp(d))
+        lib().oracle_K_apply(self.h, _dp(v), _dp(out), int(compact))
+        return out
+
+    def compact_ok(self):
+        return bool(lib().oracle_compact_ok(self.h))
 
     def vec(self, name):
         ln = _VLEN[name]

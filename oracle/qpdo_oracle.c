@@ -136,6 +136,12 @@ typedef struct {
     f64 pcg_tol; i64 pcg_maxit;
     f64 deadline;       /* absolute CLOCK_MONOTONIC seconds; 0 = none (cpu_baseline sampling only) */
     f64 *pc_r, *pc_z, *pc_p, *pc_Kp, *pc_diag, *pc_t;
+    /* compact 32-bit copies streamed by the Jacobi-PCG operator on large instances (K_apply_compact): full-symmetric
+     * CSR(Q) with its values laid out in row order, and -- rebuilt for every solve -- the weighted rows (d_i != 0)
+     * of A as CSR and the columns of A restricted to those rows */
+    int32_t *fq_ci; f64 *fq_x; int fq_valid;
+    i64 fa_k, fa_cap; i64 *fa_row, *fa_rp, *fa_cp; int32_t *fa_ci, *fa_ri; f64 *fa_rx, *fa_cx, *fa_t;
+    int progress;       /* ORACLE_PROGRESS=1: one line per loop pass on stderr (hours-long fixture runs) */
     /* info */
     i64 iterations, oterations, status_val, newton_passes, lin_iters_total;
     f64 res_prim_norm, res_dual_norm, res_prim_in_norm, res_dual_in_norm, objective;
@@ -443,6 +449,7 @@ Oracle *oracle_setup(i64 n, i64 m,
     o->sol_x = dvec(n); o->sol_y = dvec(m);
     o->reset_newton = 1;
     o->pcg_tol = 1e-12; o->pcg_maxit = 20000;
+    o->progress = getenv("ORACLE_PROGRESS") != NULL;
     build_csr_A(o);                     /* pattern + slot map; values are refreshed after the scaling */
     if (s->scaling) {
         o->scaled = 1;
@@ -871,12 +878,109 @@ static void K_apply(Oracle *o, const f64 *v, f64 *out) {
         out[j] += s;
     }
 }
+/* ---- compact operator for the hours-long full-size records ------------------------------------------------
+ * K_apply streams 16 bytes per stored entry of A (64-bit indices), all of A for the transposed half, and reaches Q
+ * through a slot map.  K_apply_compact gives the SAME BITS from a third of the traffic:
+ *  - a row r with d_r == 0 has t_r = +0.0 in K_apply, and a term A_rj * (+0.0) = (+-)0.0 never changes a column sum
+ *    that starts at +0.0 (round-to-nearest: x + (+-)0 = x for x != 0, (+0) + (+-0) = +0, and an exact cancellation
+ *    gives +0, so the running sum is never -0.0): dropping those terms keeps every bit;
+ *  - the remaining additions run in the same ascending order (columns of a row / rows of a column);
+ *  - Q's values are copied once into row order (same values, same order as Q_mv reads them).
+ * tests/test_oracle_specs.py compares both operators bit for bit. */
+static int compact_ok(const Oracle *o) {
+    return o->Arp && o->Qrp && o->A.p[o->n] > 200000 && o->n < 2000000000 && o->m < 2000000000 && !getenv("ORACLE_NO_COMPACT");
+}
+static void compact_build(Oracle *o) {
+    i64 n = o->n, m = o->m;
+    if (!o->fq_valid) {
+        i64 nz = o->Qrp[n];
+        if (!o->fq_ci) { o->fq_ci = (int32_t *)malloc((size_t)nz * sizeof(int32_t)); o->fq_x = dvec(nz); }
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static)
+        for (i64 a = 0; a < nz; a++) { o->fq_ci[a] = (int32_t)o->Qci[a]; o->fq_x[a] = o->Q.x[o->Qmap[a]]; }
+        o->fq_valid = 1;
+    }
+    if (!o->fa_row) { o->fa_row = ivec(m); o->fa_rp = ivec(m + 1); o->fa_cp = ivec(n + 1); o->fa_t = dvec(m); }
+    i64 *cidx = o->ls_idx;          /* scratch, 2m entries, free between line searches: row -> compact index */
+    i64 k = 0;
+    o->fa_rp[0] = 0;
+    for (i64 r = 0; r < m; r++) {
+        cidx[r] = -1;
+        if (o->d[r] != 0.0) { cidx[r] = k; o->fa_row[k] = r; o->fa_rp[k+1] = o->fa_rp[k] + (o->Arp[r+1] - o->Arp[r]); k++; }
+    }
+    o->fa_k = k;
+    i64 nz = o->fa_rp[k];
+    if (nz > o->fa_cap) {
+        free(o->fa_ci); free(o->fa_ri); free(o->fa_rx); free(o->fa_cx);
+        o->fa_cap = nz + nz / 8 + 1024;
+        o->fa_ci = (int32_t *)malloc((size_t)o->fa_cap * sizeof(int32_t)); o->fa_ri = (int32_t *)malloc((size_t)o->fa_cap * sizeof(int32_t));
+        o->fa_rx = dvec(o->fa_cap); o->fa_cx = dvec(o->fa_cap);
+    }
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static)
+    for (i64 c = 0; c < k; c++) {
+        i64 r = o->fa_row[c], dst = o->fa_rp[c];
+        for (i64 a = o->Arp[r]; a < o->Arp[r+1]; a++, dst++) { o->fa_ci[dst] = (int32_t)o->Aci[a]; o->fa_rx[dst] = o->Arx[a]; }
+    }
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static)
+    for (i64 j = 0; j < n; j++) {
+        i64 c = 0;
+        for (i64 a = o->A.p[j]; a < o->A.p[j+1]; a++) c += (cidx[o->A.i[a]] >= 0);
+        o->fa_cp[j+1] = c;
+    }
+    o->fa_cp[0] = 0;
+    for (i64 j = 0; j < n; j++) o->fa_cp[j+1] += o->fa_cp[j];
+#pragma omp parallel for num_threads(oracle_threads()) schedule(static)
+    for (i64 j = 0; j < n; j++) {
+        i64 dst = o->fa_cp[j];
+        for (i64 a = o->A.p[j]; a < o->A.p[j+1]; a++) {
+            i64 c = cidx[o->A.i[a]];
+            if (c >= 0) { o->fa_ri[dst] = (int32_t)c; o->fa_cx[dst] = o->A.x[a]; dst++; }
+        }
+    }
+}
+static void K_apply_compact(Oracle *o, const f64 *v, f64 *out) {
+    i64 n = o->n, k = o->fa_k;
+    f64 *t = o->fa_t;
+    const f64 sf = o->sigma_f;
+#pragma omp parallel num_threads(oracle_threads())
+    {
+#pragma omp for schedule(static) nowait
+        for (i64 r = 0; r < n; r++) {
+            f64 s = 0.0;
+            for (i64 a = o->Qrp[r]; a < o->Qrp[r+1]; a++) s += o->fq_x[a] * v[o->fq_ci[a]];
+            out[r] = s + sf * v[r];
+        }
+#pragma omp for schedule(static)
+        for (i64 c = 0; c < k; c++) {
+            f64 s = 0.0;
+            for (i64 a = o->fa_rp[c]; a < o->fa_rp[c+1]; a++) s += o->fa_rx[a] * v[o->fa_ci[a]];
+            t[c] = s * o->d[o->fa_row[c]];
+        }
+#pragma omp for schedule(static)
+        for (i64 j = 0; j < n; j++) {
+            f64 s = 0.0;
+            for (i64 a = o->fa_cp[j]; a < o->fa_cp[j+1]; a++) s += o->fa_cx[a] * t[o->fa_ri[a]];
+            out[j] += s;
+        }
+    }
+}
+/* test hook: out = K v through either operator, for the (sigma_f, d) held by the workspace */
+void oracle_K_apply(Oracle *o, const f64 *v, f64 *out, int compact) {
+    if (!o->pc_t) o->pc_t = dvec(o->m);
+    if (compact) { compact_build(o); K_apply_compact(o, v, out); } else K_apply(o, v, out);
+}
+void oracle_set_factor_state(Oracle *o, f64 sigma_f, const f64 *d) {
+    o->sigma_f = sigma_f; memcpy(o->d, d, (size_t)o->m * sizeof(f64));
+}
+int oracle_compact_ok(const Oracle *o) { return compact_ok(o); }
+
 static i64 pcg_solve(Oracle *o, const f64 *b, f64 *x) {
     i64 n = o->n, m = o->m;
     if (!o->pc_r) {
         o->pc_r = dvec(n); o->pc_z = dvec(n); o->pc_p = dvec(n); o->pc_Kp = dvec(n);
         o->pc_diag = dvec(n); o->pc_t = dvec(m);
     }
+    const int compact = compact_ok(o);
+    if (compact) compact_build(o);
     f64 *r = o->pc_r, *z = o->pc_z, *p = o->pc_p, *Kp = o->pc_Kp, *dg = o->pc_diag;
     for (i64 j = 0; j < n; j++) dg[j] = o->sigma_f;
     for (i64 j = 0; j < n; j++)
@@ -894,7 +998,7 @@ static i64 pcg_solve(Oracle *o, const f64 *b, f64 *x) {
     i64 it = 0;
     for (; it < o->pcg_maxit; it++) {
         if (o->deadline > 0 && now_s() > o->deadline) break;
-        K_apply(o, p, Kp);
+        if (compact) K_apply_compact(o, p, Kp); else K_apply(o, p, Kp);
         f64 alpha = rz / vec_prod(p, Kp, n);
         for (i64 i = 0; i < n; i++) { x[i] += alpha * p[i]; r[i] -= alpha * Kp[i]; }
         f64 rn = sqrt(vec_prod(r, r, n));
@@ -1245,6 +1349,10 @@ void oracle_solve(Oracle *o) {
         }
         o->run_time = o->setup_time + (now_s() - t0);
         tr = &o->trace[o->ntrace - 1]; tr->t_end = now_s() - t0;
+        if (o->progress)
+            fprintf(stderr, "[oracle] pass %ld kind %d act %ld +%ld -%ld tau %.6e rp %.3e rd %.3e rpi %.3e rdi %.3e lin %ld t %.0f s\n",
+                    (long)iter, (int)tr->kind, (long)tr->n_active, (long)tr->n_enter, (long)tr->n_leave, tr->tau, tr->res_prim, tr->res_dual,
+                    tr->res_prim_in, tr->res_dual_in, (long)tr->lin_iters, tr->t_end);
         if (o->run_time > o->s.max_time) { o->status_val = ST_MAX_TIME; break; }
         if (o->deadline > 0 && now_s() > o->deadline) { o->status_val = ST_MAX_TIME; break; }   /* cpu_baseline sampling */
     }
@@ -1281,6 +1389,7 @@ void oracle_update_q(Oracle *o, const f64 *q) {
         vec_scale(o->q, o->sc_c, n);
         f64 f = o->sc_c / c_old;
         for (i64 k = 0; k < o->Q.p[n]; k++) o->Q.x[k] *= f;
+        o->fq_valid = 0;
         vec_scale(o->Qx, o->sc_c / c_old, n);
         if (o->s.proximal) {
             o->sigma = o->s.sigma_init;
@@ -1308,7 +1417,7 @@ void oracle_update_settings(Oracle *o, const OracleSettings *s) {
         for (i64 i = 0; i < n; i++) o->Dinv[i] = 1.0 / o->D[i];
         for (i64 i = 0; i < m; i++) o->Einv[i] = 1.0 / o->E[i];
         o->sc_cinv = 1 / o->sc_c;
-        refresh_csr_A(o); o->factor_valid = 0;
+        refresh_csr_A(o); o->factor_valid = 0; o->fq_valid = 0;
         free(Dsave); free(Esave);
     }
     o->s = *s;
@@ -1359,6 +1468,8 @@ void oracle_cleanup(Oracle *o) {
     free(o->ls_delta); free(o->ls_alpha); free(o->ls_t); free(o->ls_idx); free(o->ls_L); free(o->ls_P); free(o->ls_J);
     free(o->active); free(o->active_old); free(o->enter); free(o->leave); free(o->d); free(o->K);
     free(o->pc_r); free(o->pc_z); free(o->pc_p); free(o->pc_Kp); free(o->pc_diag); free(o->pc_t);
+    free(o->fq_ci); free(o->fq_x); free(o->fa_row); free(o->fa_rp); free(o->fa_cp); free(o->fa_ci); free(o->fa_ri);
+    free(o->fa_rx); free(o->fa_cx); free(o->fa_t);
     free(o->sol_x); free(o->sol_y); free(o->trace);
     free(o);
 }

@@ -41,8 +41,11 @@ CASES = {
     "C4_first16": (dict(cfg="C4", index=0), dict(max_iter=16)),
     "C4_first32": (dict(cfg="C4", index=0), dict(max_iter=32)),
     "C4_first40": (dict(cfg="C4", index=0), dict(max_iter=40)),
+    # the whole solve of the metric's configuration (round 3: the oracle's PCG operator streams compact 32-bit copies,
+    # bit-identical to its plain loops -- tests/test_oracle_specs.py -- which makes the 65 passes a matter of hours)
+    "C4_full": (dict(cfg="C4", index=0), dict()),
 }
-LINSOLVE = {"C4_first16": "pcg", "C4_first32": "pcg", "C4_first40": "pcg"}
+LINSOLVE = {"C4_first16": "pcg", "C4_first32": "pcg", "C4_first40": "pcg", "C4_full": "pcg"}
 TRACE_FIELDS = ["kind", "n_active", "n_enter", "n_leave", "factor_branch", "tau", "res_prim", "res_dual",
                 "res_prim_in", "res_dual_in", "sigma", "eps_in", "lin_iters", "t_end"]
 
@@ -70,7 +73,7 @@ def main():
                     oracle_seconds=time.time() - t0, threads=os.cpu_count(), oracle_linsolve=LINSOLVE.get(name, "dense"),
                     oracle_lin_iters=i.get("lin_iters", 0))
         arrays = {f: np.array([t[f] for t in tr]) for f in TRACE_FIELDS}
-        path = os.path.join(HERE, "big_%s.npz" % name)
+        path = os.path.join(os.environ.get("GOLDEN_OUT", HERE), "big_%s.npz" % name)
         np.savez_compressed(path, meta=json.dumps(meta), x=r["x"], y=r["y"], **{"tr_" + k: v for k, v in arrays.items()})
         o.close()
         print("wrote %s (%d bytes): status %d, %d passes (%d outer), %.0f s" % (

@@ -177,3 +177,38 @@ def test_parallel_ruiz_scaling_equals_numpy_restatement_bit_for_bit():
         D *= Dt; E *= Et
     assert np.array_equal(o.vec("D"), D) and np.array_equal(o.vec("E"), E)
     o.close()
+
+
+def test_compact_pcg_operator_is_bit_identical():
+    """The compact 32-bit operator behind the oracle's Jacobi-PCG on large instances (K_apply_compact: weighted rows
+    only, Q values in row order) must give the same bits as the plain one (K_apply), including weights that are
+    zero on most rows, negative zeros in the input, and a whole solve through either operator."""
+    import os
+    p = problems.random_qp(77, 3000, 6000, 0.03, 200)
+    o = ob.OracleSolver(p, ob.default_settings(), linsolve="pcg", pcg_tol=1e-12, pcg_maxit=5000)
+    assert o.compact_ok()
+    rng = np.random.default_rng(3)
+    for frac in (0.0, 0.02, 0.4, 1.0):
+        d = np.where(rng.random(6000) < frac, 10.0 ** rng.uniform(-3, 9, 6000), 0.0)
+        v = rng.standard_normal(3000)
+        v[::17] = 0.0
+        v[5::29] = -0.0
+        a = o.K_apply(v, 1e-3, d, 0)
+        b = o.K_apply(v, 1e-3, d, 1)
+        assert a.tobytes() == b.tobytes()
+    r1 = o.solve()
+    t1 = o.trace()
+    o.close()
+    os.environ["ORACLE_NO_COMPACT"] = "1"
+    try:
+        o2 = ob.OracleSolver(p, ob.default_settings(), linsolve="pcg", pcg_tol=1e-12, pcg_maxit=5000)
+        assert not o2.compact_ok()
+        r2 = o2.solve()
+        t2 = o2.trace()
+        o2.close()
+    finally:
+        del os.environ["ORACLE_NO_COMPACT"]
+    assert r1["x"].tobytes() == r2["x"].tobytes() and r1["y"].tobytes() == r2["y"].tobytes()
+    assert r1["info"]["iterations"] == r2["info"]["iterations"] and r1["info"]["lin_iters"] == r2["info"]["lin_iters"]
+    for a, b in zip(t1, t2):
+        assert all(a[k] == b[k] for k in a if k != "t_end")
