@@ -39,8 +39,15 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "OMP_NUM_THREADS" not in os.en
         _aff = os.cpu_count() or 1
     os.environ["OMP_NUM_THREADS"] = str(max(1, _aff // int(os.environ["WORLD_SIZE"])))
 
+# The reference never resets info->status_val between solves (quirk Q1, src/qpdo.c:451-453, replicated by default): steps 2..K of a
+# workspace would report the first step's status even if they ran out of iterations.  The benchmark switches the quirk off so that
+# `status_val` of every step is that step's own outcome (and checks the reported norms against eps_abs besides).
+os.environ["QPDO_FIX_STATUS_RESET"] = "1"
+
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
 C3_COUNT = 4096           # BASELINE.json configs[2]
+MFMA_PROFILE = "r02_c2_dense_mfma_util_wide.json"   # (re-collected whenever k_ldl_syrk changes)
+PMC_PROFILE = "r03_pmc_schur_inner_c4.json"     # HBM-traffic counters of the dominant kernel (tools/pmc_collect.sh writes it)
 
 
 def parse():
@@ -260,6 +267,47 @@ def small_kernel_roofline(newton_passes, seconds, n_gpus):
                 note="latency-bound; HBM traffic is the problem data once, LDS bandwidth use is a few percent")
 
 
+def row_partition_extra(a, rank, world, dist):
+    """N > 1, default (independent-QP) mode: a short measurement of north_star's OTHER multi-GPU mode in the same run --
+    ONE instance of the workload (seed 0) with the rows of A partitioned over the ranks and an all-reduce of A'y per
+    product (RCCL on the solver's stream; QPDO_BENCH_ROWS_BACKEND=host: torch.distributed on host buffers, for ranks that
+    share a GPU) -- so that one driver SCALE run captures both modes.  Not part of `value`.  The first `passes` loop passes
+    of a cold solve (max_iter = passes), once to warm up and once timed, bracketed by barriers; max over ranks."""
+    from qpdo_amd import problems, solver
+    passes = int(os.environ.get("QPDO_BENCH_ROWS_PASSES", "16"))
+    mode = os.environ.get("QPDO_BENCH_ROWS_BACKEND", "rccl")
+    res = dict(workload="%s seed 0, rows of A partitioned over %d ranks, the first %d loop passes of a cold solve (max_iter=%d)" % (a.workload, world, passes, passes),
+               backend="RCCL all-reduce on the solver's stream" if mode == "rccl" else "torch.distributed (gloo) on host buffers")
+    try:
+        prob = problems.config_qp(a.workload, index=0)
+        s = None
+        times = []
+        for rep in range(2):
+            if solver.dist_config(rank, world, mode=mode) != 0:          # an RCCL unique id is one-shot: a fresh one per workspace
+                raise RuntimeError("qpdo_amd_dist_config failed")
+            t0 = time.time()
+            s = solver.QPDO().setup(prob["Q"], prob["q"], prob["A"], prob["l"], prob["u"], Qstype=-1, verbose=0, max_iter=passes)
+            t_setup = time.time() - t0
+            barrier(dist)
+            t0 = time.time()
+            r = s.solve()
+            solver.lib().qpdo_amd_sync(s._w)
+            barrier(dist)
+            times.append(time.time() - t0)
+            stt = s.stats()
+            s.delete()
+        dt = allreduce(dist, [times[-1]], "max")[0]
+        res.update(seconds=dt, setup_s=t_setup, newton_passes=stt["newton_passes"], newton_iters_per_s=stt["newton_passes"] / dt,
+                   iterations=r["info"]["iterations"], status_val=r["info"]["status_val"], cg_iters=stt["lin_iters"],
+                   collectives=stt["collectives"], inner_collectives=stt["inner_collectives"], inner_steps=stt["inner_steps"],
+                   inner_solves=stt["inner_solves"], schur_passes=stt["schur_passes"], scaling="strong")
+    except Exception as e:
+        res["error"] = repr(e)
+    finally:
+        solver.dist_config(0, 1)
+    return res
+
+
 def main():
     a = parse()
     rank, world, dist = dist_setup(a.gpus)
@@ -314,6 +362,7 @@ def main():
     newton = cg = 0
     iters = oters = 0
     statuses = []
+    converged = []
     at_time = at_n = 0.0
     ac_time = ac_bytes = ac_n = 0.0
     schur_passes = 0
@@ -324,6 +373,7 @@ def main():
         newton += stt["newton_passes"]; cg += stt["lin_iters"]
         iters += r["info"]["iterations"]; oters += r["info"]["oterations"]
         statuses.append(r["info"]["status_val"])
+        converged.append(bool(r["info"]["res_prim_norm"] <= 1e-6 and r["info"]["res_dual_norm"] <= 1e-6))
         at_time += stt["spmv_Q_avg_s"] * stt["spmv_Q_samples"]; at_n += stt["spmv_Q_samples"]
         ac_time += stt["spmv_Ac_time_s"]; ac_bytes += stt["spmv_Ac_bytes"]; ac_n += stt["spmv_Ac_samples"]; schur_passes += stt["schur_passes"]
     for _, sj in ws:
@@ -378,11 +428,19 @@ def main():
         if a.workload == "C4":
             # HBM bytes per launch from the PMC counters cannot be collected inside this process: the figure is the average over
             # all real launches of this kernel in separate rocprofv3 --pmc passes over this same command (committed summary)
-            pin = load_profile("r02_pmc_schur_inner_c4.json")
-            if pin is not None and "k_spmv_slab<EpiSchurW>" in pin:
-                roof["traffic"] = pin["k_spmv_slab<EpiSchurW>"]["traffic_bytes_avg"]
-                roof["traffic_source"] = ("profiles/r02_pmc_schur_inner_c4.json: 2*FETCH_SIZE + WRITE_SIZE averaged over the %d real launches of this "
-                                          "kernel in separate rocprofv3 --pmc passes over this command" % pin["k_spmv_slab<EpiSchurW>"]["real_launches"])
+            pin = load_profile(PMC_PROFILE)
+            ent = pin.get("k_spmv_slab<EpiSchurW>") if pin is not None else None
+            live = ac_bytes / ac_n
+            if ent is not None and ent.get("alg_bytes_per_launch_avg") and abs(ent["alg_bytes_per_launch_avg"] - live) <= 0.02 * live:
+                roof["traffic"] = ent["traffic_bytes_avg"]
+                roof["traffic_age"] = pin.get("commit")
+                roof["traffic_source"] = ("profiles/%s (collected at commit %s): 2*FETCH_SIZE + WRITE_SIZE averaged over the %d real launches of this "
+                                          "kernel in separate rocprofv3 --pmc passes over this command; its launch geometry (%.1f MB algorithmic per "
+                                          "launch) matches the live one (%.1f MB)" % (PMC_PROFILE, pin.get("commit"), ent["real_launches"],
+                                                                                   ent["alg_bytes_per_launch_avg"] / 1e6, live / 1e6))
+            else:
+                roof["traffic_source"] = ("none: profiles/%s is missing, or was collected on a build whose launches of this kernel moved a different "
+                                          "number of algorithmic bytes (stale) -- re-collect with tools/pmc_collect.sh" % PMC_PROFILE)
         if at_n:
             q_t, q_b = s.bench_spmv(2, reps=5)
             roof["spmv_Q_live_GBs"] = q_b / (at_time / at_n) / 1e9
@@ -403,7 +461,7 @@ def main():
             t_, b_ = s.bench_spmv(which, reps=20)
             roof[key] = b_ / t_ / 1e9
     out = None
-    all_solved = all(v == 1 for v in statuses)
+    all_solved = all(v == 1 for v in statuses) and (all(converged) or a.max_iter > 0 or a.max_time > 0)
     if rank == 0:
         out = {
             "metric": "primal-dual Newton iters/sec (+ time-to-eps) on random sparse QP",
@@ -425,12 +483,16 @@ def main():
             # covers setup + solve (src/qpdo.c:461-464)
             "time_to_eps_s": dt_max / max(1, a.steps) if all_solved else None,
             "time_to_eps_incl_setup_s": (dt_max / max(1, a.steps) + t_setup) if all_solved else None,
-            "status_val": statuses, "iterations": iters, "oterations": oters, "newton_passes": tot_newton,
+            "status_val": statuses, "residuals_within_eps_abs": converged, "iterations": iters, "oterations": oters, "newton_passes": tot_newton,
             "cg_iters": tot_cg, "kkt_prim": rp, "kkt_dual": rd,
             "setup_s": t_setup, "generate_s": t_gen,
             "roofline": roof,
         }
     s.delete()
+    if world > 1 and not rows_mode and not a.no_other_configs:
+        rp_extra = row_partition_extra(a, rank, world, dist)            # every rank takes part; rank 0 reports
+        if rank == 0:
+            out.setdefault("other_configs", {})["row_partition"] = rp_extra
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline_single(prob, a.cpu_seconds, "direct" if cfg["n"] <= 20000 else "pcg")

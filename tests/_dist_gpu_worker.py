@@ -1,12 +1,14 @@
-"""Worker for tests/test_gpu_dist.py: two (or more) ranks share GPU 0; the row-partitioned solver exchanges
-through a gloo host callback.  Rank 0 compares with the oracle and prints one JSON line."""
+"""Worker for tests/test_gpu_dist.py.  Default: two (or more) ranks share GPU 0 and the row-partitioned solver exchanges
+through a gloo host callback.  QPDO_TEST_DIST_MODE=rccl: one rank per GPU (device = LOCAL_RANK), the exchange is RCCL on
+the solver's stream (needs as many GPUs as ranks).  Rank 0 compares with the oracle and prints one JSON line."""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["QPDO_DEVICE"] = "0"
+MODE = os.environ.get("QPDO_TEST_DIST_MODE", "host")
+os.environ["QPDO_DEVICE"] = os.environ.get("LOCAL_RANK", "0") if MODE == "rccl" else "0"
 import numpy as np                              # noqa: E402
 import torch.distributed as dist                # noqa: E402
 from oracle import binding as ob                # noqa: E402
@@ -14,13 +16,13 @@ from qpdo_amd import problems, solver           # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-assert solver.dist_config(rank, world, mode="host") == 0
 out = []
 for name, p, st in [("C1", problems.config_qp("C1"), dict(max_iter=200)),
                     ("rand_eq", problems.random_qp(23, 150, 300, 0.05, 50), {}),
                     ("kat_pinf", problems.infeasibility_kat("primal_infeasible"), dict(max_iter=100)),
                     ("noscale", problems.random_qp(24, 300, 200, 0.03), dict(scaling=0)),
                     ("schur", problems.random_qp(61, 700, 1400, 0.03, 0), {})]:   # enough active rows for the Schur-complement mode
+    assert solver.dist_config(rank, world, mode=MODE) == 0      # (an RCCL unique id is one-shot: a fresh one per workspace)
     r = solver.solve_problem(p, verbose=0, **st)
     if rank == 0:
         o = ob.OracleSolver(p, ob.default_settings(**st)); ro = o.solve()

@@ -34,6 +34,61 @@ def test_row_partitioned_solve_matches_oracle(world, gpu_required):
     assert sch["collectives"] > sch["inner_collectives"]
 
 
+def test_row_partitioned_solve_over_rccl_with_two_gpus(gpu_required):
+    """The same five instances with the exchange over RCCL, one process per GPU (north star: "a single very large QP
+    row-partitions A across GPUs with an RCCL all-reduce of A'y over xGMI").  Needs two GPUs: collected everywhere, skipped
+    on a one-GPU box -- the day the suite runs on a multi-GPU node this is where ncclAllReduce first sees two ranks."""
+    from qpdo_amd import solver
+    if solver.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL cannot put two ranks on one device); this box has %d" % solver.device_count())
+    env = dict(os.environ, QPDO_TEST_DIST_MODE="rccl")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29596", os.path.join(ROOT, "tests", "_dist_gpu_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("[{")][-1])
+    for r in res:
+        assert r["ok_counts"] and r["err"] <= 1e-8 and r["linsolve"] == 0, r
+    sch = [r for r in res if r["name"] == "schur"][0]
+    assert sch["schur_passes"] > 0 and sch["inner_collectives"] == sch["inner_steps"] + sch["inner_solves"]
+
+
+def test_row_partitioned_c4_matches_fixture(gpu_required):
+    """BASELINE.json configs[3] at FULL size in its row-partitioned form (reference loop
+    src/qpdo.c:343-449): n=1e5, m=2e5, 1 % fill through the partitioned code path -- unfused epilogues behind every
+    exchange, partitioned k-vectors in the Schur-complement mode, every collective through ncclAllReduce on the solver's
+    stream (forced single-rank communicator: the one GPU of the box) -- against the oracle's record of the first 40 passes
+    (tests/golden/big_C4_first40.npz; its first 16 passes are big_C4_first16's): per-pass integers identical, tau / norms /
+    iterate after 40 passes within the PCG tolerances, one collective per inner iteration."""
+    code = r"""
+import json, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+for k in [k for k in os.environ if k.startswith("QPDO_")]: del os.environ[k]
+os.environ["QPDO_DEVICE"] = "0"
+import numpy as np
+from helpers import assert_same_trace, trace_from_npz, close_vec, ITERATE_RTOL_PCG
+from qpdo_amd import problems, solver
+z = np.load(os.path.join(%r, "tests", "golden", "big_C4_first40.npz"))
+meta = json.loads(str(z["meta"]))
+assert solver.dist_config(0, 1, mode="rccl", force=True) == 0
+p = problems.config_qp("C4", 0)
+r = solver.solve_problem(p, verbose=0, **meta["settings"])
+gi, oi = r["info"], meta["info"]
+assert (gi["status_val"], gi["iterations"], gi["oterations"]) == (oi["status_val"], oi["iterations"], oi["oterations"]), gi
+assert_same_trace(r["trace"], trace_from_npz(z), pcg=True)
+assert close_vec(r["x"], z["x"], ITERATE_RTOL_PCG) and close_vec(r["y"], z["y"], ITERATE_RTOL_PCG)
+st = r["stats"]
+print(json.dumps(dict(ok=True, ex=float(np.abs(r["x"] - z["x"]).max()), ey=float(np.abs(r["y"] - z["y"]).max()),
+                      stats={k: st[k] for k in ("linsolve", "schur_passes", "collectives", "inner_steps", "inner_solves", "inner_collectives")})))
+""" % (ROOT, ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    st = r["stats"]
+    assert r["ok"] and st["linsolve"] == 0 and st["schur_passes"] >= 30
+    assert st["inner_collectives"] == st["inner_steps"] + st["inner_solves"] and st["collectives"] > st["inner_collectives"]
+
+
 def test_sharded_batch_two_processes_bit_identical_to_oracle(gpu_required):
     """BASELINE.json configs[2] across ranks: two processes share the one GPU, rank r solves
     items r::2 of a batch of C3 instances with ONE fused-kernel launch and no collective; every item must carry the
@@ -96,7 +151,9 @@ def test_bench_contract_with_two_ranks_on_one_gpu(workload, extra, gpu_required)
     C3: the batch sharded over the ranks"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29613" if workload == "C2" else "29614", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload] + extra
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    # both ranks share the one GPU, where RCCL cannot form a 2-rank communicator: the row-partitioned extra of the default mode
+    # exchanges through torch.distributed on host buffers here (a multi-GPU node uses RCCL)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, QPDO_BENCH_ROWS_BACKEND="host", QPDO_BENCH_ROWS_PASSES="8"))
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                  # rank 0 only
@@ -105,5 +162,9 @@ def test_bench_contract_with_two_ranks_on_one_gpu(workload, extra, gpu_required)
     if workload == "C2":
         assert d["scaling"] == "weak" and d["config"]["instances_per_rank"] == 2 and all(v == 1 for v in d["status_val"])
         assert d["newton_passes"] > 2 * 3 * 30               # both ranks' passes are in the aggregate
+        # north_star's second multi-GPU mode rides along in the same run: ONE instance, rows of A partitioned over the ranks
+        rp = d["other_configs"]["row_partition"]
+        assert "error" not in rp, rp
+        assert rp["iterations"] == 8 and rp["seconds"] > 0 and rp["collectives"] > 0 and rp["newton_passes"] >= 6
     else:
         assert d["scaling"] == "strong" and d["items"] == 2 * 512 and d["failed"] == 0
