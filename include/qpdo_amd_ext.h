@@ -132,6 +132,22 @@ long qpdo_amd_solve_batch(long count, QPDOAmdBatchItem *items, const QPDOSetting
 /* HIP-event duration of the fused kernel launch of the last qpdo_amd_solve_batch on this process (0 if it took the threaded path) */
 double qpdo_amd_batch_kernel_seconds(void);
 
+/* ---- STREAMED batches (BASELINE.json configs[2]: "batch of 4096 MPC-sized QPs ... streamed") ----------------------------
+ * A fused-kernel launch is as slow as its slowest item: an instance that never reaches eps_abs (in the reference either)
+ * holds one workgroup for max_iter passes while the other CUs idle.  A batch stream keeps up to `depth` batches in flight,
+ * each on its own HIP stream with its own device arena and pinned staging: submit packs, uploads and launches batch i+1 and
+ * returns; its workgroups fill the CUs that the stragglers of batch i do not occupy.  Per item the arithmetic is that of
+ * qpdo_amd_solve_batch (same kernel): results do not depend on what else is in flight.
+ * submit: ticket >= 0, or -1 (invalid settings / data, an item that does not fit the fused kernel -- use
+ * qpdo_amd_solve_batch for those --, no free slot: wait for the oldest ticket first).  The items and everything they point
+ * to must stay valid and untouched until wait(ticket) has returned; wait fills x, y and info of every item and returns 0
+ * (-1: device error or unknown ticket), optionally the HIP-event duration of that batch's kernel. */
+typedef struct QPDOAmdBatchStream_ QPDOAmdBatchStream;
+QPDOAmdBatchStream *qpdo_amd_batch_stream_create(int depth);
+long qpdo_amd_batch_stream_submit(QPDOAmdBatchStream *stream, long count, QPDOAmdBatchItem *items, const QPDOSettings *settings);
+int  qpdo_amd_batch_stream_wait(QPDOAmdBatchStream *stream, long ticket, double *kernel_seconds);
+void qpdo_amd_batch_stream_destroy(QPDOAmdBatchStream *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -899,3 +899,27 @@ long qpdo_amd_solve_batch(long count, QPDOAmdBatchItem *items, const QPDOSetting
     for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
     return b.failed;
 }
+
+/* streamed batches: see include/qpdo_amd_ext.h */
+QPDOAmdBatchStream *qpdo_amd_batch_stream_create(int depth) {
+    int ndev = qdev_device_count();
+    if (ndev <= 0) { QPDO_EPRINT("no HIP device available (this library has no CPU path)"); return NULL; }
+    int device = env_int("QPDO_DEVICE", env_int("LOCAL_RANK", 0)) % ndev;
+    return (QPDOAmdBatchStream *)qdev_small_stream_create(device, depth);
+}
+long qpdo_amd_batch_stream_submit(QPDOAmdBatchStream *stream, long count, QPDOAmdBatchItem *items, const QPDOSettings *settings) {
+    if (!stream || count <= 0 || !items || !settings) return -1;
+    if (!validate_settings(settings)) return -1;
+    if (!qdev_small_eligible(count, items)) { QPDO_EPRINT("batch stream: an item does not fit the fused kernel (n, m <= 1024); use qpdo_amd_solve_batch"); return -1; }
+    for (long i = 0; i < count; i++) if (!validate_data(items[i].data)) return -1;
+    const long t = qdev_small_stream_submit(stream, count, items, settings);
+    if (t < 0) QPDO_EPRINT("batch stream: %s", qdev_small_last_error());
+    return t;
+}
+int qpdo_amd_batch_stream_wait(QPDOAmdBatchStream *stream, long ticket, double *kernel_seconds) {
+    if (!stream) return -1;
+    const int rc = qdev_small_stream_wait(stream, ticket, kernel_seconds);
+    if (rc) QPDO_EPRINT("batch stream: %s", qdev_small_last_error());
+    return rc;
+}
+void qpdo_amd_batch_stream_destroy(QPDOAmdBatchStream *stream) { qdev_small_stream_destroy(stream); }

@@ -156,6 +156,11 @@ int qdev_small_eligible(long count, const void *items);
 int qdev_small_batch(int device, long count, void *items, const void *settings);
 const char *qdev_small_last_error(void);
 double qdev_small_last_kernel_seconds(void);
+/* batch stream: up to `depth` fused-kernel batches in flight, each on its own HIP stream */
+void *qdev_small_stream_create(int device, int depth);
+long  qdev_small_stream_submit(void *stream, long count, void *items, const void *settings);
+int   qdev_small_stream_wait(void *stream, long ticket, double *kernel_seconds);
+void  qdev_small_stream_destroy(void *stream);
 
 #ifdef __cplusplus
 }

@@ -754,12 +754,26 @@ static void sym_full32(const cholmod_sparse *Q, HostCsr32 &o) {            // fu
         }
     }
 }
-// device arena kept between calls (hipMalloc/hipFree of ~0.5 GB cost ~0.1 s per batch); grow-only, one batch at a time
-static std::mutex s_arena_mu;
-static char *s_arena = nullptr; static size_t s_arena_cap = 0; static int s_arena_dev = -1;
-// host staging (inputs, outputs) and the per-item conversion buffers are kept as well, grow-only: releasing them cost 0.10 s per
-// 4096-item batch (36 k vector frees + unmapping 0.3 GB) and faulting the pages back in another 0.02 s
-static char *s_hin = nullptr, *s_hout = nullptr; static size_t s_hin_cap = 0, s_hout_cap = 0;
+// One in-flight batch owns a SLOT: a stream, a device arena, pinned host staging for the inputs, the outputs and the per-item
+// control structs, and the per-item conversion buffers -- all grow-only and kept between batches (hipMalloc/hipFree of ~0.5 GB
+// cost ~0.1 s per batch; releasing the host buffers another 0.1 s).  qdev_small_batch uses one static slot; a batch STREAM
+// (qdev_small_stream_*) owns `depth` slots, so that batch i+1 is packed, uploaded and started while the slowest workgroups of
+// batch i still run: a launch is as slow as its slowest item (an instance that never reaches eps runs max_iter passes on one
+// workgroup), and with one batch at a time the other CUs idle behind it.
+struct Lay { size_t Arp, Aci, Aval, Trp, Tci, Tval, Qrp, Qci, Qval, q, l, u, x0, y0, nv, mv, lsv, iv, K, solx, soly, dx, dy; HostCsr32 A, T, Q; };
+struct SmallSlot {
+    int device = -1;
+    hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    char *arena = nullptr; size_t arena_cap = 0;
+    SmallQP *dprobs = nullptr; size_t dprobs_cap = 0;
+    char *hin = nullptr, *hout = nullptr; size_t hin_cap = 0, hout_cap = 0;      // pinned: the copies must not block the host
+    SmallQP *hp = nullptr; size_t hp_cap = 0;                                   // pinned image of the per-item structs
+    long long *dprof = nullptr;
+    std::vector<Lay> lay;
+    // the batch in flight
+    long count = 0; QPDOAmdBatchItem *items = nullptr; size_t upload_bytes = 0, out_bytes = 0; bool busy = false; long ticket = -1;
+    double kernel_s = 0.0;
+};
 // run f(i) for i in [0, count) on up to 16 host threads
 template <class F>
 static void parallel_items(long count, F f) {
@@ -772,54 +786,44 @@ static void parallel_items(long count, F f) {
     for (long t = 0; t < T; t++) th.emplace_back([=]() { for (long i = t; i < count; i += T) f(i); });
     for (auto &x : th) x.join();
 }
-
-extern "C" {
-
-const char *qdev_small_last_error(void) { return s_err; }
-static double s_last_kernel_s = 0.0;          // HIP-event duration of the last k_small_solve launch (bench.py's latency statement)
-double qdev_small_last_kernel_seconds(void) { return s_last_kernel_s; }
-
-// 1 if every item fits the fused kernel
-int qdev_small_eligible(long count, const void *items_) {
-    const QPDOAmdBatchItem *items = (const QPDOAmdBatchItem *)items_;
-    for (long i = 0; i < count; i++) {
-        const QPDOData *d = items[i].data;
-        if (!d || !d->Q || !d->A) return 0;
-        if (d->n < 1 || d->n > SM_MAX_N || d->m > SM_MAX_M) return 0;
-        // the checks qpdo_setup makes before it touches a matrix (qpdo_api.c sparse_ok + dimensions): anything else goes to
-        // the generic path, which rejects it with a message instead of indexing out of bounds here
-        const cholmod_sparse *Ms[2] = {d->Q, d->A};
-        for (int k = 0; k < 2; k++) {
-            const cholmod_sparse *M = Ms[k];
-            if (!M->p || (M->itype != 0 && M->itype != 2) || M->xtype != 1 || M->dtype != 0) return 0;
-            if (!M->packed && M->nz) return 0;
-            const long long nnz = idx_at(M->p, M->itype, (long long)M->ncol);
-            if (nnz < 0 || nnz >= 2147483647LL || (nnz > 0 && (!M->i || !M->x))) return 0;
-        }
-        if (d->Q->nrow != d->n || d->Q->ncol != d->n || d->A->nrow != d->m || d->A->ncol != d->n) return 0;
-        if (!d->q || (d->m > 0 && (!d->l || !d->u))) return 0;
-    }
-    return 1;
+static void slot_release(SmallSlot &S) {
+    if (S.device >= 0) (void)hipSetDevice(S.device);
+    if (S.stream) (void)hipStreamSynchronize(S.stream);
+    if (S.dprobs) (void)hipFree(S.dprobs);
+    if (S.dprof) (void)hipFree(S.dprof);
+    if (S.arena) (void)hipFree(S.arena);
+    if (S.hin) (void)hipHostFree(S.hin);
+    if (S.hout) (void)hipHostFree(S.hout);
+    if (S.hp) (void)hipHostFree(S.hp);
+    if (S.ev0) (void)hipEventDestroy(S.ev0);
+    if (S.ev1) (void)hipEventDestroy(S.ev1);
+    if (S.stream) (void)hipStreamDestroy(S.stream);
+    S = SmallSlot();
 }
+static int pinned_reserve(char **buf, size_t *cap, size_t need) {
+    if (*cap >= need && *buf) return 0;
+    if (*buf) (void)hipHostFree(*buf);
+    *buf = nullptr; *cap = 0;
+    const size_t want = need + need / 8 + 4096;
+    if (hipHostMalloc((void **)buf, want, hipHostMallocDefault) != hipSuccess) { *buf = nullptr; return -1; }
+    *cap = want;
+    return 0;
+}
+static double s_last_kernel_s = 0.0;          // HIP-event duration of the last finished k_small_solve launch (bench.py's latency statement)
 
-// Solve all items with the fused kernel on `device`.  Returns 0 on success.
-int qdev_small_batch(int device, long count, void *items_, const void *settings_) {
-    QPDOAmdBatchItem *items = (QPDOAmdBatchItem *)items_;
-    const QPDOSettings *settings = (const QPDOSettings *)settings_;
+// pack the batch into the slot's staging buffer, upload, launch, enqueue the downloads: returns without waiting for the GPU
+static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *items, const QPDOSettings *settings) {
     int rc = 0;
-    std::lock_guard<std::mutex> arena_lock(s_arena_mu);
-    char *dbase = nullptr; hipStream_t stream = nullptr; SmallQP *dprobs = nullptr; long long *dprof = nullptr; hipEvent_t evk0 = nullptr, evk1 = nullptr;
-    char *harena = nullptr, *hout = nullptr; std::vector<SmallQP> hp((size_t)count);
     const bool tprof = getenv("QPDO_SMALL_PROF") && !strcmp(getenv("QPDO_SMALL_PROF"), "2");
     auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
     double tp0 = now();
     auto lap = [&](const char *what) { if (tprof) { const double t = now(); fprintf(stderr, "[qpdo_small host] %-22s %.3f s\n", what, t - tp0); tp0 = t; } };
     size_t total = 0;
     auto reserve = [&](size_t bytes) { size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; };
-    struct Lay { size_t Arp, Aci, Aval, Trp, Tci, Tval, Qrp, Qci, Qval, q, l, u, x0, y0, nv, mv, lsv, iv, K, solx, soly, dx, dy; HostCsr32 A, T, Q; };
-    static std::vector<Lay> lay_cache;                 // (one batch at a time: s_arena_mu is held)
-    if (lay_cache.size() < (size_t)count) lay_cache.resize((size_t)count);
-    std::vector<Lay> &lay = lay_cache;
+    if (S.device >= 0 && S.device != device) slot_release(S);
+    S.device = device;
+    if (S.lay.size() < (size_t)count) S.lay.resize((size_t)count);
+    std::vector<Lay> &lay = S.lay;
     // device arena: [inputs of all items][outputs of all items][scratch]; only the inputs are uploaded and only the
     // outputs come back.  The per-item conversions and the copies into the staging buffer run on host threads.
     parallel_items(count, [&](long i) { const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i]; csc_to_csr32(d->A, L.A); csc_as_csrT32(d->A, L.T); sym_full32(d->Q, L.Q); });
@@ -846,10 +850,11 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
         L.nv = reserve((size_t)NV_COUNT * n * 8); L.mv = reserve((size_t)MV_COUNT * m * 8 + 8); L.lsv = reserve(4 * m * 8 + 8);
         L.iv = reserve(3 * m * 4 + 4); L.K = reserve(n * n * 8);
     }
-    if (s_hin_cap < upload_bytes) { free(s_hin); s_hin = (char *)malloc(upload_bytes ? upload_bytes : 1); s_hin_cap = s_hin ? upload_bytes : 0; }
-    if (s_hout_cap < out_bytes) { free(s_hout); s_hout = (char *)malloc(out_bytes ? out_bytes : 1); s_hout_cap = s_hout ? out_bytes : 0; }
-    harena = s_hin; hout = s_hout;
-    if (!harena || !hout) { snprintf(s_err, sizeof(s_err), "host staging allocation failed"); return -1; }
+    char *harena = nullptr, *dbase = nullptr; SmallQP *hp = nullptr;
+    SHIP(hipSetDevice(device));
+    if (pinned_reserve(&S.hin, &S.hin_cap, upload_bytes ? upload_bytes : 1) || pinned_reserve(&S.hout, &S.hout_cap, out_bytes ? out_bytes : 1) ||
+        pinned_reserve((char **)&S.hp, &S.hp_cap, (size_t)count * sizeof(SmallQP))) { snprintf(s_err, sizeof(s_err), "pinned host staging allocation failed"); return -1; }
+    harena = S.hin; hp = S.hp;
     parallel_items(count, [&](long i) {
         const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
         const size_t n = d->n, m = d->m;
@@ -864,15 +869,16 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
         if (items[i].y0 && m) memcpy(h + L.y0, items[i].y0, m * 8);
     });
     lap("staging fill");
-    SHIP(hipSetDevice(device));
-    SHIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    if (s_arena && (s_arena_dev != device || s_arena_cap < total)) { (void)hipFree(s_arena); s_arena = nullptr; s_arena_cap = 0; }
-    if (!s_arena) { SHIP(hipMalloc((void **)&s_arena, total)); s_arena_cap = total; s_arena_dev = device; }
-    dbase = s_arena;
-    SHIP(hipMalloc((void **)&dprobs, (size_t)count * sizeof(SmallQP)));
+    if (!S.stream) SHIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    if (!S.ev0) { SHIP(hipEventCreate(&S.ev0)); SHIP(hipEventCreate(&S.ev1)); }
+    if (S.arena && S.arena_cap < total) { (void)hipFree(S.arena); S.arena = nullptr; S.arena_cap = 0; }
+    if (!S.arena) { SHIP(hipMalloc((void **)&S.arena, total)); S.arena_cap = total; }
+    if (S.dprobs && S.dprobs_cap < (size_t)count) { (void)hipFree(S.dprobs); S.dprobs = nullptr; S.dprobs_cap = 0; }
+    if (!S.dprobs) { SHIP(hipMalloc((void **)&S.dprobs, (size_t)count * sizeof(SmallQP))); S.dprobs_cap = (size_t)count; }
+    dbase = S.arena;
     lap("hipMalloc");
-    SHIP(hipMemcpyAsync(dbase, harena, upload_bytes, hipMemcpyHostToDevice, stream));
-    if (tprof) { SHIP(hipStreamSynchronize(stream)); lap("upload"); }
+    SHIP(hipMemcpyAsync(dbase, harena, upload_bytes, hipMemcpyHostToDevice, S.stream));
+    if (tprof) { SHIP(hipStreamSynchronize(S.stream)); lap("upload"); }
     for (long i = 0; i < count; i++) {
         const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i]; SmallQP &p = hp[(size_t)i];
         memset(&p, 0, sizeof(p));
@@ -888,13 +894,14 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
     }
     {
         const char *pf = getenv("QPDO_SMALL_PROF");
+        if (S.dprof) { (void)hipFree(S.dprof); S.dprof = nullptr; }
         if (pf && !strcmp(pf, "1")) {
-            SHIP(hipMalloc((void **)&dprof, (size_t)count * PH_COUNT * sizeof(long long)));
-            SHIP(hipMemsetAsync(dprof, 0, (size_t)count * PH_COUNT * sizeof(long long), stream));
-            for (long i = 0; i < count; i++) hp[(size_t)i].prof = dprof + i * PH_COUNT;
+            SHIP(hipMalloc((void **)&S.dprof, (size_t)count * PH_COUNT * sizeof(long long)));
+            SHIP(hipMemsetAsync(S.dprof, 0, (size_t)count * PH_COUNT * sizeof(long long), S.stream));
+            for (long i = 0; i < count; i++) hp[(size_t)i].prof = S.dprof + i * PH_COUNT;
         }
     }
-    SHIP(hipMemcpyAsync(dprobs, hp.data(), (size_t)count * sizeof(SmallQP), hipMemcpyHostToDevice, stream));
+    SHIP(hipMemcpyAsync(S.dprobs, hp, (size_t)count * sizeof(SmallQP), hipMemcpyHostToDevice, S.stream));
     {
         size_t nmax = 1, mmax = 0;
         for (long i = 0; i < count; i++) { if (items[i].data->n > nmax) nmax = items[i].data->n; if (items[i].data->m > mmax) mmax = items[i].data->m; }
@@ -908,46 +915,130 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
         lds += (klds_ok && kbytes > lsbytes) ? kbytes : lsbytes;
         SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(budget)));
         if (const char *pad = getenv("QPDO_SMALL_LDS_MIN")) { const size_t v = (size_t)atol(pad); if (v > lds && v <= budget) lds = v; }   // occupancy experiments
-        if (!evk0) { SHIP(hipEventCreate(&evk0)); SHIP(hipEventCreate(&evk1)); }
-        SHIP(hipEventRecord(evk0, stream));
-        hipLaunchKernelGGL(k_small_solve, dim3((unsigned)count), dim3(SM_THREADS), lds, stream, dprobs, (int)count, *settings, klds_ok);
-        SHIP(hipEventRecord(evk1, stream));
+        SHIP(hipEventRecord(S.ev0, S.stream));
+        hipLaunchKernelGGL(k_small_solve, dim3((unsigned)count), dim3(SM_THREADS), lds, S.stream, S.dprobs, (int)count, *settings, klds_ok);
+        SHIP(hipEventRecord(S.ev1, S.stream));
     }
     SHIP(hipGetLastError());
-    SHIP(hipMemcpyAsync(hp.data(), dprobs, (size_t)count * sizeof(SmallQP), hipMemcpyDeviceToHost, stream));
-    if (tprof) { SHIP(hipStreamSynchronize(stream)); lap("kernel"); }
-    SHIP(hipMemcpyAsync(hout, dbase + upload_bytes, out_bytes, hipMemcpyDeviceToHost, stream));
-    SHIP(hipStreamSynchronize(stream));
-    { float ms = 0.f; if (evk0 && hipEventElapsedTime(&ms, evk0, evk1) == hipSuccess) s_last_kernel_s = (double)ms * 1e-3; }
-    lap("download");
-    if (dprof) {   // diagnostic: phase shares of the longest-running item
+    SHIP(hipMemcpyAsync(hp, S.dprobs, (size_t)count * sizeof(SmallQP), hipMemcpyDeviceToHost, S.stream));
+    SHIP(hipMemcpyAsync(S.hout, dbase + upload_bytes, out_bytes, hipMemcpyDeviceToHost, S.stream));
+    S.count = count; S.items = items; S.upload_bytes = upload_bytes; S.out_bytes = out_bytes; S.busy = true;
+    lap("enqueue");
+done:
+    return rc;
+}
+// wait for the slot's batch and hand the results to its items
+static int slot_finish(SmallSlot &S) {
+    int rc = 0;
+    if (!S.busy) return 0;
+    const long count = S.count; QPDOAmdBatchItem *items = S.items; const size_t upload_bytes = S.upload_bytes;
+    SHIP(hipSetDevice(S.device));
+    SHIP(hipStreamSynchronize(S.stream));
+    { float ms = 0.f; if (hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess) { S.kernel_s = (double)ms * 1e-3; s_last_kernel_s = S.kernel_s; } }
+    if (S.dprof) {   // diagnostic: phase shares of the longest-running item
         std::vector<long long> hpf((size_t)count * PH_COUNT);
-        SHIP(hipMemcpy(hpf.data(), dprof, hpf.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        SHIP(hipMemcpy(hpf.data(), S.dprof, hpf.size() * sizeof(long long), hipMemcpyDeviceToHost));
         long best = 0; long long bt = -1;
         for (long i = 0; i < count; i++) { long long t = 0; for (int k = 0; k < PH_COUNT; k++) t += hpf[(size_t)i * PH_COUNT + k]; if (t > bt) { bt = t; best = i; } }
         static const char *nm[PH_COUNT] = {"resid", "outer", "prep", "assemble", "factor", "solve", "spmv", "linesearch", "update"};
-        fprintf(stderr, "[qpdo_small prof] item %ld, %ld passes, ticks(100MHz):", best, (long)hp[(size_t)best].info.iterations);
+        fprintf(stderr, "[qpdo_small prof] item %ld, %ld passes, ticks(100MHz):", best, (long)S.hp[(size_t)best].info.iterations);
         for (int k = 0; k < PH_COUNT; k++) fprintf(stderr, " %s=%.1fms", nm[k], hpf[(size_t)best * PH_COUNT + k] * 1e-5);
         fprintf(stderr, "\n");
     }
-    for (long i = 0; i < count; i++) {
-        const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
+    parallel_items(count, [&](long i) {
+        const QPDOData *d = items[i].data; Lay &L = S.lay[(size_t)i];
         const size_t n = d->n, m = d->m;
-        items[i].info = hp[(size_t)i].info;
+        items[i].info = S.hp[(size_t)i].info;
         const long stv = items[i].info.status_val;
-        const double *sx = (const double *)(hout + (L.solx - upload_bytes)), *sy = (const double *)(hout + (L.soly - upload_bytes));
+        const double *sx = (const double *)(S.hout + (L.solx - upload_bytes)), *sy = (const double *)(S.hout + (L.soly - upload_bytes));
         const bool infeasible = (stv == QPDO_PRIMAL_INFEASIBLE) || (stv == QPDO_DUAL_INFEASIBLE);
         if (items[i].x) for (size_t k = 0; k < n; k++) items[i].x[k] = infeasible ? NAN : sx[k];
         if (items[i].y) for (size_t k = 0; k < m; k++) items[i].y[k] = infeasible ? NAN : sy[k];
-    }
-    lap("unpack");
+    });
 done:
-    if (dprobs) (void)hipFree(dprobs);
-    if (dprof) (void)hipFree(dprof);
-    if (evk0) (void)hipEventDestroy(evk0);
-    if (evk1) (void)hipEventDestroy(evk1);
-    if (stream) (void)hipStreamDestroy(stream);
+    S.busy = false;
     return rc;
+}
+
+struct SmallStream { int device; std::vector<SmallSlot> slots; long next_ticket = 0; std::mutex mu; };
+static std::mutex s_slot0_mu;
+static SmallSlot s_slot0;                      // the one-batch-at-a-time entry point's slot
+
+extern "C" {
+
+const char *qdev_small_last_error(void) { return s_err; }
+double qdev_small_last_kernel_seconds(void) { return s_last_kernel_s; }
+
+// 1 if every item fits the fused kernel
+int qdev_small_eligible(long count, const void *items_) {
+    const QPDOAmdBatchItem *items = (const QPDOAmdBatchItem *)items_;
+    for (long i = 0; i < count; i++) {
+        const QPDOData *d = items[i].data;
+        if (!d || !d->Q || !d->A) return 0;
+        if (d->n < 1 || d->n > SM_MAX_N || d->m > SM_MAX_M) return 0;
+        // the checks qpdo_setup makes before it touches a matrix (qpdo_api.c sparse_ok + dimensions): anything else goes to
+        // the generic path, which rejects it with a message instead of indexing out of bounds here
+        const cholmod_sparse *Ms[2] = {d->Q, d->A};
+        for (int k = 0; k < 2; k++) {
+            const cholmod_sparse *M = Ms[k];
+            if (!M->p || (M->itype != 0 && M->itype != 2) || M->xtype != 1 || M->dtype != 0) return 0;
+            if (!M->packed && M->nz) return 0;
+            const long long nnz = idx_at(M->p, M->itype, (long long)M->ncol);
+            if (nnz < 0 || nnz >= 2147483647LL || (nnz > 0 && (!M->i || !M->x))) return 0;
+        }
+        if (d->Q->nrow != d->n || d->Q->ncol != d->n || d->A->nrow != d->m || d->A->ncol != d->n) return 0;
+        if (!d->q || (d->m > 0 && (!d->l || !d->u))) return 0;
+    }
+    return 1;
+}
+
+// Solve all items with the fused kernel on `device`, one batch at a time.  Returns 0 on success.
+int qdev_small_batch(int device, long count, void *items_, const void *settings_) {
+    std::lock_guard<std::mutex> lock(s_slot0_mu);
+    int rc = slot_submit(s_slot0, device, count, (QPDOAmdBatchItem *)items_, (const QPDOSettings *)settings_);
+    if (rc == 0) rc = slot_finish(s_slot0);
+    else s_slot0.busy = false;
+    return rc;
+}
+
+// ---- batch stream: up to `depth` batches in flight on `device`, each on its own HIP stream -------------------------------
+void *qdev_small_stream_create(int device, int depth) {
+    if (depth < 1) depth = 1;
+    if (depth > 64) depth = 64;
+    SmallStream *T = new SmallStream();
+    T->device = device; T->slots.resize((size_t)depth);
+    return T;
+}
+// Packs and starts the batch; returns a ticket (>= 0) without waiting for the GPU, or -1.  The items (and everything they
+// point to) must stay valid and untouched until qdev_small_stream_wait(ticket) returns.  If all slots are busy the oldest
+// batch in flight must be waited for first: the call fails rather than blocking behind it.
+long qdev_small_stream_submit(void *h, long count, void *items_, const void *settings_) {
+    SmallStream *T = (SmallStream *)h;
+    std::lock_guard<std::mutex> lock(T->mu);
+    for (SmallSlot &S : T->slots) {
+        if (S.busy) continue;
+        if (slot_submit(S, T->device, count, (QPDOAmdBatchItem *)items_, (const QPDOSettings *)settings_) != 0) { S.busy = false; return -1; }
+        S.ticket = T->next_ticket++;
+        return S.ticket;
+    }
+    snprintf(s_err, sizeof(s_err), "batch stream: all %zu slots are in flight (wait for a ticket first)", T->slots.size());
+    return -1;
+}
+// Blocks until the batch of `ticket` is complete and its items hold their results.  0 ok, -1 error / unknown ticket.
+int qdev_small_stream_wait(void *h, long ticket, double *kernel_seconds) {
+    SmallStream *T = (SmallStream *)h;
+    SmallSlot *S = nullptr;
+    { std::lock_guard<std::mutex> lock(T->mu); for (SmallSlot &c : T->slots) if (c.busy && c.ticket == ticket) S = &c; }
+    if (!S) { snprintf(s_err, sizeof(s_err), "batch stream: ticket %ld is not in flight", ticket); return -1; }
+    const int rc = slot_finish(*S);
+    if (kernel_seconds) *kernel_seconds = S->kernel_s;
+    return rc;
+}
+void qdev_small_stream_destroy(void *h) {
+    SmallStream *T = (SmallStream *)h;
+    if (!T) return;
+    for (SmallSlot &S : T->slots) { if (S.busy) (void)slot_finish(S); slot_release(S); }
+    delete T;
 }
 
 }  // extern "C"

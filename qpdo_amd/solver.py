@@ -102,7 +102,8 @@ class BatchItem(C.Structure):
     _fields_ = [("data", C.POINTER(QPDOData)), ("x0", dp), ("y0", dp), ("x", dp), ("y", dp), ("info", QPDOInfo)]
 
 
-EXT_SYMBOLS = ["qpdo_amd_dist_config", "qpdo_amd_dist_unique_id", "qpdo_amd_solve_batch", "qpdo_amd_batch_kernel_seconds", "qpdo_amd_device_count", "qpdo_amd_last_error", "qpdo_amd_get_stats", "qpdo_amd_get_trace",
+EXT_SYMBOLS = ["qpdo_amd_dist_config", "qpdo_amd_dist_unique_id", "qpdo_amd_solve_batch", "qpdo_amd_batch_kernel_seconds", "qpdo_amd_batch_stream_create",
+               "qpdo_amd_batch_stream_submit", "qpdo_amd_batch_stream_wait", "qpdo_amd_batch_stream_destroy", "qpdo_amd_device_count", "qpdo_amd_last_error", "qpdo_amd_get_stats", "qpdo_amd_get_trace",
                "qpdo_amd_sync", "qpdo_amd_bench_spmv", "qpdo_amd_bench_dense_factor", "qpdo_amd_spmv", "qpdo_amd_linesearch", "qpdo_amd_download"]
 
 _lib = None
@@ -138,6 +139,13 @@ def lib():
         L.qpdo_amd_solve_batch.restype = C.c_long
         L.qpdo_amd_batch_kernel_seconds.restype = C.c_double
         L.qpdo_amd_solve_batch.argtypes = [C.c_long, C.POINTER(BatchItem), C.POINTER(QPDOSettings), C.c_int]
+        L.qpdo_amd_batch_stream_create.restype = C.c_void_p
+        L.qpdo_amd_batch_stream_create.argtypes = [C.c_int]
+        L.qpdo_amd_batch_stream_submit.restype = C.c_long
+        L.qpdo_amd_batch_stream_submit.argtypes = [C.c_void_p, C.c_long, C.POINTER(BatchItem), C.POINTER(QPDOSettings)]
+        L.qpdo_amd_batch_stream_wait.restype = C.c_int
+        L.qpdo_amd_batch_stream_wait.argtypes = [C.c_void_p, C.c_long, C.POINTER(C.c_double)]
+        L.qpdo_amd_batch_stream_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -392,6 +400,10 @@ class Batch:
             settings = default_settings(**kw)
         failed = lib().qpdo_amd_solve_batch(len(self.outs), self.items, C.byref(settings), int(nthreads))
         self.kernel_seconds = float(lib().qpdo_amd_batch_kernel_seconds())
+        return self.results(), int(failed)
+
+    def results(self):
+        """list of dicts (info, x, y) from the items' output fields (after run(), or after BatchStream.wait)"""
         names = [f for f, _ in QPDOInfo._fields_]
         res = []
         for i, (x, y) in enumerate(self.outs):
@@ -399,7 +411,51 @@ class Batch:
             info = {f: getattr(inf, f) for f in names}
             info["status"] = info["status"].decode()
             res.append(dict(info=info, x=x.copy(), y=y.copy()))
-        return res, int(failed)
+        return res
+
+
+class BatchStream:
+    """Up to `depth` fused-kernel batches in flight on this process's GPU (qpdo_amd_batch_stream_*): submit() packs, uploads
+    and launches a Batch and returns a ticket without waiting for the GPU; wait(ticket) blocks until that batch is complete
+    and returns (results, kernel_seconds).  A Batch object may be in flight only once at a time (its items hold the output
+    buffers)."""
+
+    def __init__(self, depth=8):
+        self._h = lib().qpdo_amd_batch_stream_create(int(depth))
+        if not self._h:
+            raise RuntimeError("qpdo_amd_batch_stream_create failed")
+        self._inflight = {}
+
+    def submit(self, batch, settings=None, **kw):
+        if settings is None:
+            settings = default_settings(**kw)
+        if any(b is batch for b, _ in self._inflight.values()):
+            raise ValueError("this Batch is already in flight")
+        t = int(lib().qpdo_amd_batch_stream_submit(self._h, len(batch.outs), batch.items, C.byref(settings)))
+        if t < 0:
+            raise RuntimeError("qpdo_amd_batch_stream_submit failed: " + lib().qpdo_amd_last_error().decode())
+        self._inflight[t] = (batch, settings)
+        return t
+
+    def wait(self, ticket):
+        batch, _ = self._inflight.pop(ticket)
+        ks = C.c_double(0.0)
+        if lib().qpdo_amd_batch_stream_wait(self._h, int(ticket), C.byref(ks)) != 0:
+            raise RuntimeError("qpdo_amd_batch_stream_wait failed: " + lib().qpdo_amd_last_error().decode())
+        batch.kernel_seconds = float(ks.value)
+        return batch.results(), float(ks.value)
+
+    def close(self):
+        if self._h:
+            lib().qpdo_amd_batch_stream_destroy(self._h)
+            self._h = None
+            self._inflight.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_indices(count, rank, world):

@@ -102,6 +102,44 @@ def test_fused_batch_sweep_is_bit_identical(gpu_required):
     assert not bad, bad
 
 
+def test_streamed_overlapping_batches_are_bit_identical(gpu_required):
+    """BASELINE.json configs[2] "streamed": three batches in flight at once on a batch stream (qpdo_amd_batch_stream_*) -- the
+    same 120 varied instances split 50 / 40 / 30, the first with max_iter large enough that its slow items are still running
+    while the next two are packed, uploaded and launched.  What else is in flight must not matter: every item carries the
+    oracle's counts and the oracle's bits, exactly as in the one-launch sweep above; tickets can be waited for out of order."""
+    probs = [_instance(i)[0] for i in range(120)]
+    parts = [probs[:50], probs[50:90], probs[90:]]
+    batches = [solver.Batch(pp) for pp in parts]
+    st = solver.BatchStream(depth=3)
+    tickets = [st.submit(b, verbose=0, max_iter=300) for b in batches]
+    with pytest.raises(RuntimeError):
+        st.submit(solver.Batch(probs[:2]), verbose=0)          # all three slots busy: refused, not blocked
+    out = {}
+    for k in (1, 0, 2):
+        out[k], ks = st.wait(tickets[k])
+        assert ks > 0.0
+    res = out[0] + out[1] + out[2]
+    # a slot is free again: a second round through the same stream, one batch alone
+    t = st.submit(batches[2], verbose=0, max_iter=300)
+    again, _ = st.wait(t)
+    st.close()
+    assert all(np.array_equal(a["x"], b["x"], equal_nan=True) and a["info"]["iterations"] == b["info"]["iterations"] for a, b in zip(again, out[2]))
+    bad = []
+    for i, (p, r) in enumerate(zip(probs, res)):
+        o = ob.OracleSolver(p, ob.default_settings(max_iter=300))
+        ro = o.solve()
+        oi, ox, oy = dict(ro["info"]), np.array(ro["x"]), np.array(ro["y"])
+        o.close()
+        gi = r["info"]
+        ok = (gi["status_val"], gi["iterations"], gi["oterations"]) == (oi["status_val"], oi["iterations"], oi["oterations"])
+        if ok and oi["status_val"] not in (-3, -4):
+            ok = np.array_equal(r["x"], ox) and np.array_equal(r["y"], oy) and gi["objective"] == oi["objective"] \
+                and gi["res_prim_norm"] == oi["res_prim_norm"] and gi["res_dual_norm"] == oi["res_dual_norm"]
+        if not ok:
+            bad.append((i, p["n"], p["m"], oi["status_val"], gi["status_val"], oi["iterations"], gi["iterations"]))
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("i", range(6))
 def test_schur_mode_mid_size_instances_match_oracle(i, gpu_required, monkeypatch):
     """instances large enough (k >= 256 active rows) for the Schur-complement mode of the PCG, with equality rows,
