@@ -64,6 +64,8 @@ def parse():
                     help="N > 1: 'independent' = one QP per GPU, no collective (weak scaling, default); 'rows' = ONE QP whose "
                          "rows of A are partitioned over the GPUs with RCCL all-reduces (strong scaling)")
     ap.add_argument("--batch-count", type=int, default=C3_COUNT, help="C3: number of QPs in the whole batch")
+    ap.add_argument("--stream-depth", type=int, default=int(os.environ.get("QPDO_BENCH_STREAM_DEPTH", "12")),
+                    help="C3: batches in flight on the batch stream (1 = one launch at a time, each step waited for before the next)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="bound of the cpu_baseline sample of the main workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the informational C2 / C3-batch measurements")
@@ -209,18 +211,44 @@ def run_batch(a, rank, world, dist):
     t_gen = time.time() - t0
     for _ in range(max(1, a.warmup)):          # at least one: device arena + code objects
         B.run(**st)
+    # "streamed" (BASELINE.json configs[2]): with more than one step the steps go through a batch stream, up to --stream-depth of
+    # them in flight (step s+1 is packed, uploaded and launched while the slowest workgroups of step s still run); every step is
+    # still one pass over the whole batch and every item of every step is waited for inside the timed region.
+    depth = max(1, min(a.stream_depth, a.steps))
+    images = [B] + [solver.Batch(B.probs, indices=B.indices) for _ in range(depth - 1)] if depth > 1 else [B]
+    stream = solver.BatchStream(depth=depth) if depth > 1 else None
+    if stream is not None:                     # warm the slots (arenas, pinned staging) outside the timed region
+        for t in [stream.submit(img, **dict(st, max_iter=50)) for img in images]:
+            stream.wait(t)
     barrier(dist)
     t0 = time.time()
     newton = solved = failed = 0
     kernel_s = 0.0
-    for _ in range(a.steps):
-        res, f = B.run(**st)
-        failed += f
-        kernel_s += B.kernel_seconds
-        newton += sum(r["info"]["iterations"] - r["info"]["oterations"] for r in res)
-        solved += sum(r["info"]["status_val"] == 1 for r in res)
+    if stream is None:
+        for _ in range(a.steps):
+            res, f = B.run(**st)
+            failed += f
+            kernel_s += B.kernel_seconds
+            newton += sum(r["info"]["iterations"] - r["info"]["oterations"] for r in res)
+            solved += sum(r["info"]["status_val"] == 1 for r in res)
+    else:
+        tickets = []
+        def collect(t):
+            nonlocal newton, solved, kernel_s
+            res, ks = stream.wait(t)
+            kernel_s += ks
+            newton += sum(r["info"]["iterations"] - r["info"]["oterations"] for r in res)
+            solved += sum(r["info"]["status_val"] == 1 for r in res)
+        for k in range(a.steps):
+            if len(tickets) == depth:
+                collect(tickets.pop(0))
+            tickets.append(stream.submit(images[k % depth], **st))
+        while tickets:
+            collect(tickets.pop(0))
     barrier(dist)
     dt = time.time() - t0
+    if stream is not None:
+        stream.close()
     dt_max = allreduce(dist, [dt], "max")[0]
     tot_newton, tot_solved, tot_failed, tot_items = allreduce(dist, [newton, solved, failed, len(B.indices) * a.steps], "sum")
     if rank != 0:
@@ -232,10 +260,11 @@ def run_batch(a, rank, world, dist):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic (seeded counter-based generator, qpdo_amd/csrc/qpdo_gen.c)",
         "config": {"workload": "C3: batch of %d MPC-sized QPs (n=%d, m=%d, %d equality rows, density %g) sharded over the GPUs "
-                               "(item b -> GPU b mod N), one fused-kernel launch per GPU and step, no collective; cold start, reference "
+                               "(item b -> GPU b mod N), one fused-kernel launch per GPU and step, %s, no collective; cold start, reference "
                                "default settings%s" % (count, cfg["n"], cfg["m"], cfg["n_eq"], cfg["density"],
+                                                       ("steps streamed, up to %d in flight" % depth) if depth > 1 else "one step at a time",
                                                        (", max_iter=%d" % a.max_iter) if a.max_iter > 0 else " (max_iter=10000)"),
-                   "count": count, "n": cfg["n"], "m": cfg["m"], "parallelism": "independent QPs, batch sharded over ranks, no collective"},
+                   "count": count, "n": cfg["n"], "m": cfg["m"], "stream_depth": depth, "parallelism": "independent QPs, batch sharded over ranks, no collective"},
         "qps_per_s": tot_items / dt_max, "solved": tot_solved, "failed": tot_failed, "items": tot_items, "generate_s": t_gen,
         "kernel_s_per_step_rank0": kernel_s / max(1, a.steps),
         "roofline": small_kernel_roofline(newton / max(1, a.steps), kernel_s / max(1, a.steps), 1),       # rank 0's launch
@@ -547,6 +576,31 @@ def main():
                 c3[label] = dict(seconds=dtb, kernel_seconds=B.kernel_seconds, qps_per_s=nb / dtb, failed=failed, newton_iters_per_s=nwt / dtb,
                                  solved=sum(r_["info"]["status_val"] == 1 for r_ in resb),
                                  roofline=small_kernel_roofline(nwt, B.kernel_seconds, 1))
+            # streamed (configs[2]): 24 consecutive batches at the reference's default settings, up to 12 in flight
+            try:
+                depth_s, nb_s = 12, 24
+                imgs = [B] + [solver.Batch(probs) for _ in range(depth_s - 1)]
+                stq = solver.BatchStream(depth=depth_s)
+                for t_ in [stq.submit(img, verbose=0, max_iter=50) for img in imgs]:
+                    stq.wait(t_)
+                t0 = time.time(); tick = []; nwt = nsolved = 0; ksum = 0.0
+                def _collect(t_):
+                    nonlocal nwt, nsolved, ksum
+                    rr, ks_ = stq.wait(t_)
+                    ksum += ks_; nwt += sum(r_["info"]["iterations"] - r_["info"]["oterations"] for r_ in rr); nsolved += sum(r_["info"]["status_val"] == 1 for r_ in rr)
+                for k_ in range(nb_s):
+                    if len(tick) == depth_s:
+                        _collect(tick.pop(0))
+                    tick.append(stq.submit(imgs[k_ % depth_s], verbose=0))
+                while tick:
+                    _collect(tick.pop(0))
+                dts = time.time() - t0
+                stq.close()
+                c3["streamed_max_iter_default_10000"] = dict(batches=nb_s, in_flight=depth_s, seconds=dts, qps_per_s=nb_s * nb / dts, newton_iters_per_s=nwt / dts,
+                                                             solved=nsolved, kernel_seconds_summed=ksum,
+                                                             note="qpdo_amd_batch_stream_*: %d consecutive batches of %d, every item waited for inside the timed region" % (nb_s, nb))
+            except Exception as e:
+                c3["streamed_max_iter_default_10000"] = dict(error=repr(e))
             c3["workload"] = "%d QPs n=120, m=360 (120 equality rows), one fused-kernel launch, wall time through the Python class" % nb
             if not a.no_cpu_baseline:
                 c3["cpu_baseline"] = cpu_baseline_batch(probs[:256], 8.0, {})

@@ -127,6 +127,12 @@ static QPDOSettings *copy_settings(const QPDOSettings *s) {   /* src/util.c:21-4
     return n;
 }
 
+/* The batch stream (qpdo_amd_batch_stream_*) keeps up to `depth` fused-kernel launches in flight on separate HIP streams.  The
+ * runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that share a queue serialise: measured
+ * on MI355X, 16 batches of 4096 C3 QPs at depth 12: 7.0 k QP/s on 4 queues, 10.1 k on 16.  The variable is read when the HIP
+ * runtime initialises (the first HIP call of the process), so it is set -- never overridden -- when this library is loaded. */
+__attribute__((constructor)) static void qpdo_amd_on_load(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 static int env_int_early(const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
 static double wall_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 /* ---- matrix intake: CSC (int32 or int64 indices) -> int32 CSR triples ------------- */

@@ -377,6 +377,7 @@ class Batch:
 
     def __init__(self, probs, indices=None):
         self.keep, self.items, self.outs = [], (BatchItem * len(probs))(), []
+        self.probs = probs
         self.indices = list(range(len(probs))) if indices is None else list(indices)   # global item numbers of this shard
         for i, p in enumerate(probs):
             A, Q = sp.csc_matrix(p["A"]), sp.csc_matrix(p["Q"])
