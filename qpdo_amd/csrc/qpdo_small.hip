@@ -947,8 +947,10 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
         SHIP(hipEventRecord(S.ev1, S.stream));
     }
     SHIP(hipGetLastError());
-    SHIP(hipMemcpyAsync(hp, S.dprobs, (size_t)count * sizeof(SmallQP), hipMemcpyDeviceToHost, S.stream));
-    SHIP(hipMemcpyAsync(S.hout, dbase + upload_bytes, out_bytes, hipMemcpyDeviceToHost, S.stream));
+    // The downloads are NOT enqueued here: a device-to-host copy waiting for this kernel would sit at the head of the copy
+    // engine's in-order ring for as long as the slowest workgroup runs, and the upload of the next batch (another stream, the
+    // same engine) would queue behind it -- measured: batches submitted 20 ms apart then ran strictly one after the other.
+    // slot_finish issues them once the kernel has completed.
     S.count = count; S.items = items; S.upload_bytes = upload_bytes; S.out_bytes = out_bytes; S.busy = true;
     lap("enqueue");
 done:
@@ -960,6 +962,9 @@ static int slot_finish(SmallSlot &S) {
     if (!S.busy) return 0;
     const long count = S.count; QPDOAmdBatchItem *items = S.items; const size_t upload_bytes = S.upload_bytes;
     SHIP(hipSetDevice(S.device));
+    SHIP(hipEventSynchronize(S.ev1));
+    SHIP(hipMemcpyAsync(S.hp, S.dprobs, (size_t)count * sizeof(SmallQP), hipMemcpyDeviceToHost, S.stream));
+    SHIP(hipMemcpyAsync(S.hout, S.arena + upload_bytes, S.out_bytes, hipMemcpyDeviceToHost, S.stream));
     SHIP(hipStreamSynchronize(S.stream));
     { float ms = 0.f; if (hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess) { S.kernel_s = (double)ms * 1e-3; s_last_kernel_s = S.kernel_s; } }
     if (S.dprof) {   // diagnostic: phase shares of the longest-running item
