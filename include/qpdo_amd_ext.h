@@ -75,6 +75,8 @@ typedef struct {
                              * and the all-reduces they issued: exactly one per launched iteration plus one per solve              */
     long   chain_fallbacks; /* dense triangular solves redone with the stepwise kernels (dense LDL')                  */
     double pcg_max_relres;  /* largest ||r||/||rhs|| a PCG solve of the last qpdo_solve ended with (tolerance QPDO_PCG_TOL)      */
+    long   pcg_dense_fallbacks; /* PCG solves that could not converge (relative residual > 1e-8: e.g. settings->proximal = 0 on a singular
+                             * Q + A'DA) and were redone by the dense LDL' solver, which the rest of that qpdo_solve then keeps (n <= 18000) */
 } QPDOAmdStats;
 
 int  qpdo_amd_device_count(void);

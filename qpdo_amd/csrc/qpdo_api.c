@@ -842,6 +842,7 @@ int qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out) {
     out->collectives = (long)st.collectives; out->inner_solves = (long)st.inner_solves;
     out->inner_steps = (long)st.inner_steps; out->inner_collectives = (long)st.inner_collectives;
     out->pcg_max_relres = st.pcg_max_relres;
+    out->pcg_dense_fallbacks = (long)st.pcg_dense_fallbacks;
     return 0;
 }
 

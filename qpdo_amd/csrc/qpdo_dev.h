@@ -51,6 +51,7 @@ typedef struct {
     int64_t inner_solves, inner_steps, inner_collectives;   /* Schur mode: inner solves, their iterations launched, their all-reduces */
     int64_t chain_fallbacks;    /* dense solves redone stepwise after a polled triangular solve lost a producer */
     double  pcg_max_relres;     /* largest relative residual ||r|| / ||rhs|| any PCG solve of the last qpdo_solve ended with   */
+    int64_t pcg_dense_fallbacks;/* PCG solves that did not converge and were redone by the dense solver */
 } QdevStats;
 
 int qdev_device_count(void);

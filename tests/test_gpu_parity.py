@@ -625,10 +625,19 @@ def test_pcg_that_cannot_converge_is_an_error_not_a_silent_step(gpu_required, mo
     monkeypatch.setenv("QPDO_LINSOLVE", "pcg")
     monkeypatch.setenv("QPDO_PCG_SCHUR", "0")
     monkeypatch.setenv("QPDO_PCG_MAXIT", "3")
+    monkeypatch.setenv("QPDO_PCG_DENSE_FALLBACK", "0")
     p = problems.random_qp(22, 150, 300, 0.05, 0)
     r = solver.solve_problem(p, verbose=0)
     assert r["info"]["status_val"] == -99
     assert "did not converge" in solver.lib().qpdo_amd_last_error().decode()
+    # default: the pass whose PCG solve cannot converge is redone by the dense LDL' solver (the reference factorizes, it never fails
+    # for lack of iterations), which the workspace then keeps: the outcome is the oracle's
+    monkeypatch.delenv("QPDO_PCG_DENSE_FALLBACK")
+    r = solver.solve_problem(p, verbose=0)
+    o = ob.OracleSolver(p, ob.default_settings()); ro = o.solve(); to = o.trace(); o.close()
+    assert r["stats"]["pcg_dense_fallbacks"] == 1 and r["stats"]["factor_count"] >= 1
+    assert_same_outcome(r, ro["info"], ro["x"], ro["y"], p)
+    assert_same_trace(r["trace"], to)
     monkeypatch.delenv("QPDO_PCG_MAXIT")
     r = solver.solve_problem(p, verbose=0)
     assert r["info"]["status_val"] == 1 and r["stats"]["pcg_soft_accepts"] == 0

@@ -80,6 +80,22 @@ def test_randomized_sweep_matches_oracle(mode, gpu_required, monkeypatch):
     assert not bad, bad
 
 
+def test_pcg_without_proximal_term_falls_back_to_the_dense_solver_not_to_an_error(gpu_required, monkeypatch):
+    """Instance 1358 of the wider one-off sweep (profiles/r02_parity_sweep_more2.txt; proximal = 0, inner_max_iter = 2): without the
+    proximal term Q + A'DA is singular to working precision there, Jacobi-PCG stagnates above 1e-8 and round 2 ended the solve with
+    QPDO_ERROR (-99) where the reference -- a direct factorization, cholmod_interface.c:35-52 -- runs on to max_iter (-5).  The pass is
+    now redone by the dense solver and the outcome must be the oracle's."""
+    monkeypatch.setenv("QPDO_LINSOLVE", "pcg")
+    p, st = _instance(1358)
+    assert st.get("proximal") == 0
+    o = ob.OracleSolver(p, ob.default_settings(**st)); ro = o.solve(); o.close()
+    r = solver.solve_problem(p, verbose=0, **st)
+    gi, oi = r["info"], ro["info"]
+    assert oi["status_val"] == -5
+    assert (gi["status_val"], gi["iterations"], gi["oterations"]) == (oi["status_val"], oi["iterations"], oi["oterations"])
+    assert r["stats"]["pcg_dense_fallbacks"] >= 1
+
+
 def test_fused_batch_sweep_is_bit_identical(gpu_required):
     """the one-workgroup-per-QP kernel on the same 120 varied instances (one launch): operation order equals the
     oracle's, so x, y, objective and residual norms must match bit for bit (NaN-filled outputs for the certificates)"""
