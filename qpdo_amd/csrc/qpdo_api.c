@@ -756,30 +756,15 @@ void qpdo_update_q(QPDOWorkspace *work, const c_float *q) {
     QpdoDev *dev = work->chol->dev;
     memcpy(work->data->q, q, n * sizeof(c_float));
     if (work->settings->scaling) {
-        c_float *Qx = malloc((n ? n : 1) * sizeof(c_float)), *x = malloc((n ? n : 1) * sizeof(c_float));
-        if (!Qx || !x || qdev_download_vec(dev, 1, Qx) || qdev_download_vec(dev, 0, x)) { free(Qx); free(x); update_status(work->info, QPDO_ERROR); return; }
-        for (size_t i = 0; i < n; i++) work->data->q[i] = work->scaling->D[i] * work->data->q[i];
-        c_float c_old = work->scaling->c;
-        if (work->settings->proximal) for (size_t i = 0; i < n; i++) Qx[i] = Qx[i] + (-work->sigma) * x[i];
-        c_float mx = 0.0;
-        for (size_t i = 0; i < n; i++) { c_float t = work->data->q[i] + work->scaling->cinv * Qx[i]; c_float s = c_absval(t); mx = s > mx ? s : mx; }
-        work->scaling->c = 1 / c_max(1.0, mx);
-        work->scaling->cinv = 1 / work->scaling->c;
-        for (size_t i = 0; i < n; i++) work->data->q[i] *= work->scaling->c;
-        const c_float f = work->scaling->c / c_old;
-        for (size_t i = 0; i < n; i++) Qx[i] *= f;
-        if (work->settings->proximal) {
-            work->sigma = work->settings->sigma_init;
-            for (size_t i = 0; i < n; i++) Qx[i] = Qx[i] + work->sigma * x[i];
-        }
-        int rc = qdev_scale_Q_values(dev, f) || qdev_upload_vec(dev, 1, Qx) || qdev_upload_q(dev, work->data->q) ||
-                 qdev_set_scaling(dev, 1, work->scaling->D, work->scaling->Dinv, work->scaling->E, work->scaling->Einv,
-                                  work->scaling->c, work->scaling->cinv);
-        c_float nq = 0.0;
-        for (size_t i = 0; i < n; i++) { c_float s = c_absval(work->scaling->Dinv[i] * work->data->q[i]); nq = s > nq ? s : nq; }
+        /* device side (round 3): Qx and x stay in HBM; the host receives the new cost scaling c and norm_q only and keeps its copy
+         * of the scaled q (work->data->q) in step by reading it back -- n doubles, instead of 2n down + 5n up before */
+        c_float c_new = 1.0, cinv_new = 1.0, nq = 0.0;
+        const c_float sigma_new = work->settings->proximal ? work->settings->sigma_init : work->sigma;
+        if (qdev_update_q_scaled(dev, q, (int)work->settings->proximal, work->sigma, sigma_new, work->scaling->c, &c_new, &cinv_new, &nq) ||
+            qdev_download_q(dev, work->data->q)) { update_status(work->info, QPDO_ERROR); return; }
+        work->scaling->c = c_new; work->scaling->cinv = cinv_new;
+        if (work->settings->proximal) work->sigma = work->settings->sigma_init;
         work->norm_q = nq;
-        free(Qx); free(x);
-        if (rc) update_status(work->info, QPDO_ERROR);
     } else {
         if (qdev_upload_q(dev, work->data->q)) update_status(work->info, QPDO_ERROR);
         work->norm_q = vec_norm_inf(work->data->q, n);

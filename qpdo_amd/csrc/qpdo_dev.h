@@ -132,6 +132,8 @@ int qdev_upload_vec(QpdoDev *d, int which, const double *src);
 int qdev_configure(QpdoDev *d, int linsolve /*0 pcg,1 dense,-1 auto*/, double pcg_tol, int pcg_maxit);
 /* the linear solves stop at pcg_tol relative OR at 1e-5 eps_abs in the reference's unscaled inf-norm of the dual residual */
 int qdev_set_eps_abs(QpdoDev *d, double eps_abs);
+int qdev_update_q_scaled(QpdoDev *d, const double *q_unscaled, int proximal, double sigma_old, double sigma_new, double c_old,
+                         double *c_new, double *cinv_new, double *norm_q);
 int qdev_get_stats(QpdoDev *d, QdevStats *out);
 int qdev_reset_stats(QpdoDev *d);
 /* HIP-event average of the Q SpMV sampled once per PCG batch during the last solve */
