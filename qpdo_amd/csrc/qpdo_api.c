@@ -582,13 +582,23 @@ void qpdo_solve(QPDOWorkspace *work) {
     be->ntrace = 0; be->newton_passes = 0;
     qdev_reset_stats(dev);
     c_int iter = 0, oter = 0, iter_old = 0;
+    long tr_pending = -1;           /* index of the trace record whose tau is still in flight (deferred step read-back) */
     if (!work->initialized) goto done;      /* warm start failed on the device */
     DEVCALL(qdev_begin_solve(dev));
     DEVCALL(qdev_set_eps_abs(dev, s->eps_abs));
+    /* One host synchronisation per loop pass instead of two (dense solver; QPDO_DEFER_STEP=0 switches it off): the Newton step is
+     * launched without waiting for it; its step length -- needed only by the trace, the iteration line and is_dual_infeasible -- comes
+     * back with the next pass's residual norms.  Printing wants tau on the pass's own line, so verbose solves keep two. */
+    DEVCALL(qdev_set_deferred_step(dev, !s->verbose && env_int("QPDO_DEFER_STEP", 1)));
 
     for (iter = 0; iter < s->max_iter; iter++) {
         QdevResid r;
         DEVCALL(qdev_residuals(dev, prox, work->sigma, &r));
+        if (r.prev_step_done) {
+            work->tau = r.prev_tau;
+            if (tr_pending >= 0 && tr_pending < be->ntrace) be->trace[tr_pending].tau = r.prev_tau;
+            tr_pending = -1;
+        }
         work->info->res_prim_norm = r.res_prim; work->info->res_dual_norm = r.res_dual;
         work->info->res_prim_in_norm = r.res_prim_in; work->info->res_dual_in_norm = r.res_dual_in;
         QPDOAmdTraceRec *tr = trace_push(be);
@@ -661,6 +671,7 @@ void qpdo_solve(QPDOWorkspace *work) {
             int lin = 0;
             DEVCALL(qdev_newton_step(dev, branch, r.n_enter + r.n_leave, prox, work->sigma, &work->tau, &lin));
             be->newton_passes++;
+            if (tr && work->tau != work->tau) tr_pending = be->ntrace - 1;        /* NaN: the step's read-back is deferred */
             if (tr) { tr->tau = work->tau; tr->n_active = r.n_active; tr->n_enter = r.n_enter; tr->n_leave = r.n_leave; tr->factor_branch = branch; tr->lin_iters = lin; }
         }
         work->info->run_time = work->info->setup_time + toc(work->timer);
@@ -669,6 +680,11 @@ void qpdo_solve(QPDOWorkspace *work) {
     if (work->info->status_val == QPDO_UNSOLVED) update_status(work->info, QPDO_MAX_ITER_REACHED);
 
 done:
+    {   /* a Newton step still in flight (loop left by max_iter / max_time right after it): complete it before the solution is stored */
+        int had = 0; c_float tau_last = 0.0;
+        if (qdev_finish_step(dev, &had, &tau_last)) { QPDO_EPRINT("device backend: %s", qdev_last_error()); update_status(work->info, QPDO_ERROR); }
+        else if (had) { work->tau = tau_last; if (tr_pending >= 0 && tr_pending < be->ntrace) be->trace[tr_pending].tau = tau_last; }
+    }
     work->info->iterations = iter;
     work->info->oterations = oter;
     /* store_solution (termination.c:82-92) + host mirrors */

@@ -32,6 +32,8 @@ typedef struct {
 typedef struct {
     double res_prim, res_dual, res_prim_in, res_dual_in;   /* inf-norms, un-scaled by Einv / Dinv */
     int32_t n_active, n_enter, n_leave;
+    /* a Newton step whose read-back was deferred (qdev_set_deferred_step) completes with the NEXT residual pass: its step length */
+    int32_t prev_step_done; double prev_tau;
 } QdevResid;
 
 /* per-solve device statistics (extension; see include/qpdo_amd_ext.h) */
@@ -134,6 +136,11 @@ int qdev_configure(QpdoDev *d, int linsolve /*0 pcg,1 dense,-1 auto*/, double pc
 int qdev_set_eps_abs(QpdoDev *d, double eps_abs);
 int qdev_update_q_scaled(QpdoDev *d, const double *q_unscaled, int proximal, double sigma_old, double sigma_new, double c_old,
                          double *c_new, double *cinv_new, double *norm_q);
+/* Deferred read-back of the Newton step (dense solver, one GPU): qdev_newton_step returns without synchronising; its step length and the
+ * lost-producer latch of the chained solves arrive with the control block of the next qdev_residuals (or qdev_finish_step): one host
+ * synchronisation per loop pass instead of two.  tau_out of qdev_newton_step is then NaN. */
+int qdev_set_deferred_step(QpdoDev *d, int on);
+int qdev_finish_step(QpdoDev *d, int *had_pending, double *tau);
 int qdev_get_stats(QpdoDev *d, QdevStats *out);
 int qdev_reset_stats(QpdoDev *d);
 /* HIP-event average of the Q SpMV sampled once per PCG batch during the last solve */
