@@ -623,17 +623,18 @@ void qpdo_solve(QPDOWorkspace *work) {
                     DEVCALL(qdev_primal_infeasibility(dev, s->eps_prim_inf, &inf));
                     if (inf) { update_status(work->info, QPDO_PRIMAL_INFEASIBLE); break; }
                 }
-                if (s->eps_dual_inf > 0) {
-                    int inf = 0;
-                    DEVCALL(qdev_dual_infeasibility(dev, prox, work->sigma, work->tau, s->eps_dual_inf, &inf));
-                    if (inf) { update_status(work->info, QPDO_DUAL_INFEASIBLE); break; }
-                }
             }
+            /* is_dual_infeasible and update_mu (iteration.c:127-168) share one read-back: update_mu is enqueued behind the test and does
+             * nothing if the test says "infeasible" (update_mu does not look at x_bar / y_bar, so running it before the estimates are
+             * shifted changes nothing) */
+            const int do_dinf = (iter < iter_old + s->inner_max_iter) && (s->eps_dual_inf > 0);
+            const int do_mu = (oter > 0) && (r.res_prim > s->eps_abs);
+            int dinf = 0, nch = 0;
+            DEVCALL(qdev_dual_infeasibility_and_mu(dev, do_dinf, prox, work->sigma, work->tau, s->eps_dual_inf, do_mu, s->eps_abs, s->theta,
+                                                   s->delta, s->mu_min, work->sqrt_mu_min, &dinf, &nch));
+            if (dinf) { update_status(work->info, QPDO_DUAL_INFEASIBLE); break; }
             DEVCALL(qdev_shift_estimates(dev));
-            if ((oter > 0) && (r.res_prim > s->eps_abs)) {
-                /* update_mu (iteration.c:127-168) */
-                int nch = 0;
-                DEVCALL(qdev_update_mu(dev, s->eps_abs, s->theta, s->delta, s->mu_min, work->sqrt_mu_min, &nch));
+            if (do_mu) {
                 work->n_mu_changed = nch;
                 if ((prox && work->sigma > s->sigma_min) || (nch > 0.25 * QPDO_MAX_RANK_UPDATE)) be->reset_newton = 1;
                 else if (nch == 0) { /* nothing */ }

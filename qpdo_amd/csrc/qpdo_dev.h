@@ -139,6 +139,8 @@ int qdev_update_q_scaled(QpdoDev *d, const double *q_unscaled, int proximal, dou
 /* Deferred read-back of the Newton step (dense solver, one GPU): qdev_newton_step returns without synchronising; its step length and the
  * lost-producer latch of the chained solves arrive with the control block of the next qdev_residuals (or qdev_finish_step): one host
  * synchronisation per loop pass instead of two.  tau_out of qdev_newton_step is then NaN. */
+int qdev_dual_infeasibility_and_mu(QpdoDev *d, int do_dinf, int proximal, double sigma, double tau, double eps_dual_inf, int do_mu,
+                                   double eps_abs, double theta, double delta, double mu_min, double isq_mu_min, int *is_infeasible, int *n_changed);
 int qdev_set_deferred_step(QpdoDev *d, int on);
 int qdev_finish_step(QpdoDev *d, int *had_pending, double *tau);
 int qdev_get_stats(QpdoDev *d, QdevStats *out);
