@@ -215,7 +215,7 @@ def run_batch(a, rank, world, dist):
     # them in flight (step s+1 is packed, uploaded and launched while the slowest workgroups of step s still run); every step is
     # still one pass over the whole batch and every item of every step is waited for inside the timed region.
     depth = max(1, min(a.stream_depth, a.steps))
-    images = [B] + [solver.Batch(B.probs, indices=B.indices) for _ in range(depth - 1)] if depth > 1 else [B]
+    images = [B] + [B.twin() for _ in range(depth - 1)] if depth > 1 else [B]
     stream = solver.BatchStream(depth=depth) if depth > 1 else None
     if stream is not None:                     # warm the slots (arenas, pinned staging) outside the timed region
         for t in [stream.submit(img, **dict(st, max_iter=50)) for img in images]:
@@ -296,44 +296,62 @@ def small_kernel_roofline(newton_passes, seconds, n_gpus):
                 note="latency-bound; HBM traffic is the problem data once, LDS bandwidth use is a few percent")
 
 
+ABANDON_COLLECTIVES = False      # set when the row-partition extra timed out: ranks may be stuck in a collective, so no further barrier
+
+
 def row_partition_extra(a, rank, world, dist):
     """N > 1, default (independent-QP) mode: a short measurement of north_star's OTHER multi-GPU mode in the same run --
     ONE instance of the workload (seed 0) with the rows of A partitioned over the ranks and an all-reduce of A'y per
     product (RCCL on the solver's stream; QPDO_BENCH_ROWS_BACKEND=host: torch.distributed on host buffers, for ranks that
     share a GPU) -- so that one driver SCALE run captures both modes.  Not part of `value`.  The first `passes` loop passes
-    of a cold solve (max_iter = passes), once to warm up and once timed, bracketed by barriers; max over ranks."""
+    of a cold solve (max_iter = passes), once to warm up and once timed, bracketed by barriers; max over ranks.
+    The RCCL exchange has never run on more than one rank before the first multi-GPU node sees this code (the build pool has one GPU
+    per box): the measurement runs on a watchdog thread, and if it has not finished within QPDO_BENCH_ROWS_TIMEOUT seconds (default
+    300) it is abandoned -- the main line is printed regardless and the process leaves without another collective."""
+    global ABANDON_COLLECTIVES
     from qpdo_amd import problems, solver
     passes = int(os.environ.get("QPDO_BENCH_ROWS_PASSES", "16"))
     mode = os.environ.get("QPDO_BENCH_ROWS_BACKEND", "rccl")
+    limit = float(os.environ.get("QPDO_BENCH_ROWS_TIMEOUT", "300"))
     res = dict(workload="%s seed 0, rows of A partitioned over %d ranks, the first %d loop passes of a cold solve (max_iter=%d)" % (a.workload, world, passes, passes),
                backend="RCCL all-reduce on the solver's stream" if mode == "rccl" else "torch.distributed (gloo) on host buffers")
+
+    def body():
+        try:
+            prob = problems.config_qp(a.workload, index=0)
+            times = []
+            for rep in range(2):
+                if solver.dist_config(rank, world, mode=mode) != 0:          # an RCCL unique id is one-shot: a fresh one per workspace
+                    raise RuntimeError("qpdo_amd_dist_config failed")
+                t0 = time.time()
+                s = solver.QPDO().setup(prob["Q"], prob["q"], prob["A"], prob["l"], prob["u"], Qstype=-1, verbose=0, max_iter=passes)
+                t_setup = time.time() - t0
+                barrier(dist)
+                t0 = time.time()
+                r = s.solve()
+                solver.lib().qpdo_amd_sync(s._w)
+                barrier(dist)
+                times.append(time.time() - t0)
+                stt = s.stats()
+                s.delete()
+            dt = allreduce(dist, [times[-1]], "max")[0]
+            res.update(seconds=dt, setup_s=t_setup, newton_passes=stt["newton_passes"], newton_iters_per_s=stt["newton_passes"] / dt,
+                       iterations=r["info"]["iterations"], status_val=r["info"]["status_val"], cg_iters=stt["lin_iters"],
+                       collectives=stt["collectives"], inner_collectives=stt["inner_collectives"], inner_steps=stt["inner_steps"],
+                       inner_solves=stt["inner_solves"], schur_passes=stt["schur_passes"], scaling="strong")
+        except Exception as e:
+            res["error"] = repr(e)
+
+    th = threading.Thread(target=body, daemon=True)
+    th.start()
+    th.join(limit)
+    if th.is_alive():
+        ABANDON_COLLECTIVES = True
+        return dict(res, error="timed out after %.0f s (abandoned; no further collective in this process)" % limit)
     try:
-        prob = problems.config_qp(a.workload, index=0)
-        s = None
-        times = []
-        for rep in range(2):
-            if solver.dist_config(rank, world, mode=mode) != 0:          # an RCCL unique id is one-shot: a fresh one per workspace
-                raise RuntimeError("qpdo_amd_dist_config failed")
-            t0 = time.time()
-            s = solver.QPDO().setup(prob["Q"], prob["q"], prob["A"], prob["l"], prob["u"], Qstype=-1, verbose=0, max_iter=passes)
-            t_setup = time.time() - t0
-            barrier(dist)
-            t0 = time.time()
-            r = s.solve()
-            solver.lib().qpdo_amd_sync(s._w)
-            barrier(dist)
-            times.append(time.time() - t0)
-            stt = s.stats()
-            s.delete()
-        dt = allreduce(dist, [times[-1]], "max")[0]
-        res.update(seconds=dt, setup_s=t_setup, newton_passes=stt["newton_passes"], newton_iters_per_s=stt["newton_passes"] / dt,
-                   iterations=r["info"]["iterations"], status_val=r["info"]["status_val"], cg_iters=stt["lin_iters"],
-                   collectives=stt["collectives"], inner_collectives=stt["inner_collectives"], inner_steps=stt["inner_steps"],
-                   inner_solves=stt["inner_solves"], schur_passes=stt["schur_passes"], scaling="strong")
-    except Exception as e:
-        res["error"] = repr(e)
-    finally:
         solver.dist_config(0, 1)
+    except Exception:
+        pass
     return res
 
 
@@ -579,7 +597,7 @@ def main():
             # streamed (configs[2]): 24 consecutive batches at the reference's default settings, up to 12 in flight
             try:
                 depth_s, nb_s = 12, 24
-                imgs = [B] + [solver.Batch(probs) for _ in range(depth_s - 1)]
+                imgs = [B] + [B.twin() for _ in range(depth_s - 1)]
                 stq = solver.BatchStream(depth=depth_s)
                 for t_ in [stq.submit(img, verbose=0, max_iter=50) for img in imgs]:
                     stq.wait(t_)
@@ -608,7 +626,9 @@ def main():
         except Exception as e:
             out.setdefault("other_configs", {})["error"] = repr(e)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if ABANDON_COLLECTIVES:
+        os._exit(0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

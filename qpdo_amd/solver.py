@@ -396,6 +396,21 @@ class Batch:
             self.items[i].x, self.items[i].y = _as_dp(x), _as_dp(y)
             self.outs.append((x, y))
 
+    def twin(self):
+        """A second host image of the same batch that shares the (read-only) problem data and has its own output buffers: several
+        twins of one Batch can be in flight on a BatchStream at once (building an image from scratch is Python / scipy work)."""
+        t = Batch.__new__(Batch)
+        t.probs, t.indices = self.probs, list(self.indices)
+        t.keep, t.items, t.outs = [self], (BatchItem * len(self.outs))(), []
+        for i in range(len(self.outs)):
+            n, m = len(self.outs[i][0]), len(self.outs[i][1])
+            x, y = np.zeros(n), np.zeros(m)
+            t.items[i].data = self.items[i].data
+            t.items[i].x0, t.items[i].y0 = self.items[i].x0, self.items[i].y0
+            t.items[i].x, t.items[i].y = _as_dp(x), _as_dp(y)
+            t.outs.append((x, y))
+        return t
+
     def run(self, settings=None, nthreads=16, **kw):
         if settings is None:
             settings = default_settings(**kw)

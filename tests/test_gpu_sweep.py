@@ -136,9 +136,12 @@ def test_streamed_overlapping_batches_are_bit_identical(gpu_required):
         assert ks > 0.0
     res = out[0] + out[1] + out[2]
     # a slot is free again: a second round through the same stream, one batch alone
-    t = st.submit(batches[2], verbose=0, max_iter=300)
+    # ... together with a twin of it (shared problem data, own output buffers), both in flight at once
+    t, t2 = st.submit(batches[2], verbose=0, max_iter=300), st.submit(batches[2].twin(), verbose=0, max_iter=300)
     again, _ = st.wait(t)
+    twin, _ = st.wait(t2)
     st.close()
+    assert all(np.array_equal(a["x"], b["x"], equal_nan=True) and np.array_equal(a["y"], b["y"], equal_nan=True) for a, b in zip(twin, again))
     assert all(np.array_equal(a["x"], b["x"], equal_nan=True) and a["info"]["iterations"] == b["info"]["iterations"] for a, b in zip(again, out[2]))
     bad = []
     for i, (p, r) in enumerate(zip(probs, res)):
