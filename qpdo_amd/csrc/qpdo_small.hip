@@ -63,7 +63,7 @@ enum { MV_Y = 0, MV_YBAR, MV_AX, MV_MU, MV_ISQ, MV_W, MV_RP, MV_RPOLD, MV_RPI, M
 
 // diagnostic phase timer: lane 0 adds wall-clock ticks (100 MHz) to a buffer no other code reads
 #define PH(k) do { if (P.prof && threadIdx.x == 0) { const long long t_ = wall_clock64(); P.prof[k] += t_ - tph; tph = t_; } } while (0)
-enum { PH_RESID = 0, PH_OUTER, PH_PREP, PH_ASM, PH_FACTOR, PH_SOLVE, PH_SPMV, PH_LS, PH_UPDATE, PH_COUNT };
+enum { PH_RESID = 0, PH_OUTER, PH_PREP, PH_ASM, PH_FACTOR, PH_SOLVE, PH_SPMV, PH_LS, PH_UPDATE, PH_LS_DOTS, PH_LS_SORT, PH_LS_JSUM, PH_LS_WALK, PH_COUNT };   // (the last four: inside PH_LS)
 #define FOR_T(i, N) for (int i = threadIdx.x; i < (N); i += blockDim.x)
 #define SYNC __syncthreads()
 
@@ -71,6 +71,31 @@ __device__ __forceinline__ double s_abs(double x) { return x < 0 ? -x : x; }
 __device__ __forceinline__ double s_max(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double s_min(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ double s_mid(double a, double lo, double hi) { return s_max(lo, s_min(a, hi)); }
+
+// Sequential left fold  acc = (..((acc + v[0]) + v[1]) + ..) + v[count-1]  -- the additions of a one-lane loop in index order, hence the
+// same bits -- executed by wave 0: its 64 lanes LOAD 64 elements at a time and the fold walks them with v_readlane (register to
+// register, ~16 cycles per element) instead of paying a dependent LDS round trip per element on one lane (measured on the batch
+// kernel's slowest items: 84 us -> 7 us for the 2m-element sums of a linesearch).  Call from all 64 lanes of wave 0.
+__device__ __forceinline__ double rl64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave0_fold(const double *v, int count, double acc) {
+    const int lane = threadIdx.x & 63;
+#pragma nounroll
+    for (int c = 0; c < count; c += 64) {
+        const double x = (c + lane < count) ? v[c + lane] : 0.0;
+        const int left = count - c;
+        if (left >= 64) {
+#pragma unroll
+            for (int l = 0; l < 64; l++) acc += rl64(x, l);
+        } else {
+#pragma unroll
+            for (int l = 0; l < 64; l++) if (l < left) acc += rl64(x, l);
+        }
+    }
+    return acc;
+}
 
 // block-wide max of non-negative values (order independent => exact); result to every thread
 __device__ double blk_max(double v, double *sm) {
@@ -108,11 +133,9 @@ __device__ double dot_seq(const double *a, const double *b, int n, double *sm, d
     FOR_T(g, ng) { const int i = 4 * g; gbuf[g] = (a[i] * b[i] + a[i + 1] * b[i + 1] + a[i + 2] * b[i + 2] + a[i + 3] * b[i + 3]); }
     FOR_T(t, n - 4 * ng) gbuf[ng + t] = a[4 * ng + t] * b[4 * ng + t];
     SYNC;
-    if (threadIdx.x == 0) {
-        double prod = 0.0;
-        for (int g = 0; g < ng; g++) prod += gbuf[g];
-        for (int t = 0; t < n - 4 * ng; t++) prod += gbuf[ng + t];
-        sm[16] = prod;
+    if (threadIdx.x < 64) {                          // the groups, then the tail, added in order (gbuf holds them back to back)
+        const double prod = wave0_fold(gbuf, ng + (n - 4 * ng), 0.0);
+        if (threadIdx.x == 0) sm[16] = prod;
     }
     SYNC;
     return sm[16];
@@ -286,8 +309,67 @@ __device__ void small_ldl_solve(SmallQP &P, const KView &kv, const double *b, do
 }
 
 // ---- linesearch (linesearch.c:8-158) -------------------------------------------------------------------
-__device__ double small_linesearch(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, unsigned char *jflag, double *tm, double *sm, u64 *skey, u32 *sidx, double *gbuf) {
+// Bitonic network on (key, index) with the elements in REGISTERS: thread t holds elements t + 512 r, r < R (R = np2 / 512, at least 1).
+// A compare-exchange whose partner is at distance j >= 512 is inside the thread, 64 <= j < 512 goes through LDS (the output arrays
+// double as the exchange buffer: write, barrier, read, barrier), j < 64 is a lane shuffle without a barrier -- 45 of the 55 stages at
+// np2 = 1024.  The network and every comparison are those of the all-LDS version it replaces (one barrier per stage): the same
+// permutation, i.e. the stable order by (t, index) of the reference's qsort.  Ends with the sorted arrays in skey / sidx.
+template <int R>
+__device__ __forceinline__ void small_sort_regs(int np2, int M2, const double *ls_alpha, const double *ls_delta, u64 *skey, u32 *sidx) {
+    u64 key[R]; u32 idx[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int e = (int)threadIdx.x + SM_THREADS * r;
+        u64 kv = ~0ull;
+        if (e < M2) { const double t = ls_alpha[e] / ls_delta[e]; if (t > 0) kv = (u64)__double_as_longlong(t); }
+        key[r] = kv; idx[r] = (u32)e;
+    }
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= SM_THREADS) {                     // partner in this thread: elements r and r ^ (j / 512)
+                const int dr = j / SM_THREADS;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if ((r & dr) == 0 && (r | dr) < R) {
+                        const int e = (int)threadIdx.x + SM_THREADS * r;
+                        const bool up = ((e & k) == 0);
+                        const bool gt = (key[r] > key[r | dr]) || (key[r] == key[r | dr] && idx[r] > idx[r | dr]);
+                        if (gt == up) { const u64 tk = key[r]; key[r] = key[r | dr]; key[r | dr] = tk; const u32 ti = idx[r]; idx[r] = idx[r | dr]; idx[r | dr] = ti; }
+                    }
+                }
+            } else {
+                u64 pk[R]; u32 pi[R];
+                if (j >= 64) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) { const int e = (int)threadIdx.x + SM_THREADS * r; if (e < np2) { skey[e] = key[r]; sidx[e] = idx[r]; } }
+                    SYNC;
+#pragma unroll
+                    for (int r = 0; r < R; r++) { const int e = (int)threadIdx.x + SM_THREADS * r; if (e < np2) { pk[r] = skey[e ^ j]; pi[r] = sidx[e ^ j]; } else { pk[r] = key[r]; pi[r] = idx[r]; } }
+                    SYNC;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; r++) { pk[r] = (u64)__shfl_xor((long long)key[r], j, 64); pi[r] = (u32)__shfl_xor((int)idx[r], j, 64); }
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int e = (int)threadIdx.x + SM_THREADS * r;
+                    const bool mine_gt = (key[r] > pk[r]) || (key[r] == pk[r] && idx[r] > pi[r]);
+                    const bool up = ((e & k) == 0), lower = ((e & j) == 0);
+                    const bool swap = lower ? (mine_gt == up) : (mine_gt != up);      // pair (i, i^j), i lower: exchanged iff (elem i > elem i^j) == up
+                    if (swap) { key[r] = pk[r]; idx[r] = pi[r]; }
+                }
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < R; r++) { const int e = (int)threadIdx.x + SM_THREADS * r; if (e < np2) { skey[e] = key[r]; sidx[e] = idx[r]; } }
+    SYNC;
+}
+// (its own function, not inlined: the kernel is held to 128 VGPRs, and inlined the register pressure of the sort and of the unrolled
+// folds below pushed spills into the factorization and solve loops -- measured: triangular solves 2x slower)
+__device__ __attribute__((noinline)) double small_linesearch(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, unsigned char *jflag, double *tm, double *sm, u64 *skey, u32 *sidx, double *gbuf) {
     const int n = P.n, m = P.m;
+    long long tls = P.prof ? wall_clock64() : 0;
+#define PHL(k) do { if (P.prof && threadIdx.x == 0) { const long long t_ = wall_clock64(); P.prof[k] += t_ - tls; tls = t_; } } while (0)
     double *dy = V[MV_DY], *mu = V[MV_MU], *isq = V[MV_ISQ], *w = V[MV_W], *y = V[MV_Y], *Adx = V[MV_ADX];
     FOR_T(i, m) { double s = dy[i] * mu[i]; s = s * 0.5; tm[i] = s; }
     double eta = dot_seq(dy, tm, m, sm, gbuf);
@@ -306,53 +388,76 @@ __device__ double small_linesearch(SmallQP &P, double *V[], double *ls_delta, do
     // candidates: key = bits(t) for t > 0, sentinel otherwise; bitonic sort on (key, idx) == stable sort by t
     const int M2 = 2 * m;
     int np2 = 1; while (np2 < M2) np2 <<= 1;
-    FOR_T(i, np2) {
-        u64 key = ~0ull;
-        if (i < M2) { const double t = ls_alpha[i] / ls_delta[i]; if (t > 0) key = (u64)__double_as_longlong(t); }
-        skey[i] = key; sidx[i] = (u32)i;
-    }
-    SYNC;
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            FOR_T(i, np2) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const u64 ka = skey[i], kb = skey[ixj]; const u32 ia = sidx[i], ib = sidx[ixj];
-                    const bool up = ((i & k) == 0);
-                    const bool gt = (ka > kb) || (ka == kb && ia > ib);
-                    if (gt == up) { skey[i] = kb; skey[ixj] = ka; sidx[i] = ib; sidx[ixj] = ia; }
-                }
-            }
-            SYNC;
-        }
-    // L / P / J flags in parallel; the J sums and the walk sequentially on one lane (linesearch.c:108-157)
+    PHL(PH_LS_DOTS);
+    if (np2 <= SM_THREADS) small_sort_regs<1>(np2, M2, ls_alpha, ls_delta, skey, sidx);
+    else if (np2 == 2 * SM_THREADS) small_sort_regs<2>(np2, M2, ls_alpha, ls_delta, skey, sidx);
+    else small_sort_regs<4>(np2, M2, ls_alpha, ls_delta, skey, sidx);
+    PHL(PH_LS_SORT);
+    // L / P / J flags in parallel; the J sums and the walk sequentially on one lane (linesearch.c:108-157).  The one-lane loops run at
+    // the latency of their dependent LDS reads unless the reads are taken out of the dependence chain: the J sums load groups of four
+    // elements before folding them (same additions, same order), and the walk reads (delta, alpha) from arrays that every thread
+    // has first rearranged INTO the sorted order (in place, through registers), so that it too can load ahead.
     FOR_T(i, M2) {
         const double dl = ls_delta[i], t = ls_alpha[i] / dl;
         const int L = t > 0, Pp = dl > 0;
         jflag[i] = (unsigned char)(L | (((Pp + L) == 1) << 1));
     }
     SYNC;
+    const int per = (M2 + (int)blockDim.x - 1) / (int)blockDim.x;          // <= 4 sorted positions per thread (2m <= 2048)
+    double gd[4], ga[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int e = (int)threadIdx.x + r * (int)blockDim.x;
+        gd[r] = 0.0; ga[r] = 0.0;
+        if (r < per && e < M2) { const u32 iz = sidx[e]; if (iz < (u32)M2) { gd[r] = ls_delta[iz]; ga[r] = ls_alpha[iz]; } }
+    }
+    // J sums by wave 0: lane l takes element c + l; an element outside J contributes +0.0, which never changes a running sum that
+    // starts at +0.0 (x + 0 = x for x != -0, and such a sum is never -0: (+0) + (-0) = +0 and an exact cancellation gives +0)
+    double sa = 0.0, sb = 0.0; int nL = 0;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+#pragma nounroll
+        for (int c = 0; c < M2; c += 64) {
+            const int i = c + lane;
+            const unsigned char f = i < M2 ? jflag[i] : 0;
+            const double dl = i < M2 ? ls_delta[i] : 0.0, al = i < M2 ? ls_alpha[i] : 0.0;
+            const double va = (f & 2) ? dl * dl : 0.0, vb = (f & 2) ? dl * al : 0.0;
+            nL += __popcll(__ballot(f & 1));
+#pragma unroll
+            for (int l = 0; l < 64; l++) { sa += rl64(va, l); sb += rl64(vb, l); }
+        }
+    }
+    PHL(PH_LS_JSUM);
+    SYNC;                                             // everyone is done with the index-ordered arrays
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int e = (int)threadIdx.x + r * (int)blockDim.x;
+        if (r < per && e < M2) { ls_delta[e] = gd[r]; ls_alpha[e] = ga[r]; }
+    }
+    SYNC;
     if (threadIdx.x == 0) {
-        double sa = 0.0, sb = 0.0; int nL = 0;
-        for (int i = 0; i < M2; i++) { nL += jflag[i] & 1; if (jflag[i] & 2) { const double dl = ls_delta[i]; sa += dl * dl; } }
-        for (int i = 0; i < M2; i++) if (jflag[i] & 2) sb += ls_delta[i] * ls_alpha[i];
         double a = eta + sa, b = beta - sb, tau;
         if (nL == 0) tau = -b / a;
         else {
             const double t0 = __longlong_as_double((long long)skey[0]);
             if (b + a * t0 > 0) tau = -b / a;
             else {
-                int i = 0, iz; bool found = false;
-                while (i < nL - 1) {
-                    iz = (int)sidx[i];
-                    const double dl = ls_delta[iz], al = ls_alpha[iz];
-                    if (dl > 0) { a = a + dl * dl; b = b - dl * al; } else { a = a - dl * dl; b = b + dl * al; }
-                    i++;
-                    if (b + a * __longlong_as_double((long long)skey[i]) > 0) { found = true; break; }
+                int i = 0; bool found = false;
+#pragma nounroll
+                while (i < nL - 1 && !found) {
+                    const int left = nL - 1 - i;
+                    double dl[4], al[4], tn[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (u < left) { dl[u] = ls_delta[i + u]; al[u] = ls_alpha[i + u]; tn[u] = __longlong_as_double((long long)skey[i + u + 1]); }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (u < left && !found) {
+                        if (dl[u] > 0) { a = a + dl[u] * dl[u]; b = b - dl[u] * al[u]; } else { a = a - dl[u] * dl[u]; b = b + dl[u] * al[u]; }
+                        i++;
+                        if (b + a * tn[u] > 0) found = true;
+                    }
                 }
                 if (!found) {
-                    iz = (int)sidx[i];
-                    const double dl = ls_delta[iz], al = ls_alpha[iz];
+                    const double dl = ls_delta[i], al = ls_alpha[i];
                     if (dl > 0) { a = a + dl * dl; b = b - dl * al; } else { a = a - dl * dl; b = b + dl * al; }
                 }
                 tau = -b / a;
@@ -360,6 +465,8 @@ __device__ double small_linesearch(SmallQP &P, double *V[], double *ls_delta, do
         }
         sm[17] = tau;
     }
+    PHL(PH_LS_WALK);
+#undef PHL
     SYNC;
     return sm[17];
 }
@@ -382,6 +489,12 @@ __device__ void small_status(QPDOInfo &info, long st) {
     info.status[i] = 0;
 }
 
+template <class T>
+__device__ __forceinline__ T *uni_ptr(T *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
 // ---- the whole solve of one QP by one workgroup ----------------------------------------------------------
 __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, int count, QPDOSettings st, int klds_ok) {
     __shared__ double sm[32];
@@ -392,7 +505,18 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
     // ~67 KB instead of ~104 KB at n = 120, m = 360: two workgroups per CU instead of one.
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     if ((int)blockIdx.x >= count) return;
-    SmallQP &P = probs[blockIdx.x];
+    // Every field of the item's descriptor is the same for all threads, but loaded from global memory it lands in VECTOR registers, and
+    // so does every pointer derived from it (~45 of them are live across the solve loop: two thirds of the 128-VGPR budget).  Passing
+    // each field through v_readfirstlane tells the compiler it is uniform: the descriptor and the address arithmetic move to SGPRs.
+    SmallQP &Pg = probs[blockIdx.x];                  // (outputs are written through this one)
+    SmallQP P;
+    P.n = __builtin_amdgcn_readfirstlane(Pg.n); P.m = __builtin_amdgcn_readfirstlane(Pg.m);
+#define UNI_PTR(f) P.f = uni_ptr(Pg.f)
+    UNI_PTR(Arp); UNI_PTR(Aci); UNI_PTR(Aval); UNI_PTR(Trp); UNI_PTR(Tci); UNI_PTR(Tval); UNI_PTR(Qrp); UNI_PTR(Qci); UNI_PTR(Qval);
+    UNI_PTR(q); UNI_PTR(l); UNI_PTR(u); UNI_PTR(x0); UNI_PTR(y0); UNI_PTR(nv); UNI_PTR(mv); UNI_PTR(lsv); UNI_PTR(iv); UNI_PTR(K);
+    UNI_PTR(sol_x); UNI_PTR(sol_y); UNI_PTR(cert_dx); UNI_PTR(cert_dy); UNI_PTR(prof);
+#undef UNI_PTR
+    P.c_const = Pg.c_const;
     const int n = P.n, m = P.m;
     // info->setup_time / solve_time / run_time of this item (reference PROFILING build, qpdo.c:79-82,327-329,461-464) and the
     // max_time limit (qpdo.c:441-447): the 100 MHz wall clock, read by one lane and broadcast so that every decision taken from
@@ -515,10 +639,9 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
                             ls_delta[2 * i + 1] = (P.l[i] > -e * SM_INFTY) ? P.l[i] * s_min(dy[i], 0) : 0;
                         }
                         SYNC;
-                        if (threadIdx.x == 0) {
-                            double oob = 0;
-                            for (int i = 0; i < 2 * m; i++) oob += ls_delta[i];
-                            sm[18] = oob;
+                        if (threadIdx.x < 64) {
+                            const double oobs = wave0_fold(ls_delta, 2 * m, 0.0);
+                            if (threadIdx.x == 0) sm[18] = oobs;
                         }
                         SYNC;
                         const double oob = sm[18];
@@ -713,15 +836,15 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
         }
         if (scaled) obj *= sc_cinv;
         obj += P.c_const;
-        P.info.iterations = iter; P.info.oterations = oter;
-        P.info.res_prim_norm = rpn; P.info.res_dual_norm = rdn; P.info.res_prim_in_norm = rpin; P.info.res_dual_in_norm = rdin;
-        P.info.objective = obj;
+        Pg.info.iterations = iter; Pg.info.oterations = oter;
+        Pg.info.res_prim_norm = rpn; Pg.info.res_dual_norm = rdn; Pg.info.res_prim_in_norm = rpin; Pg.info.res_dual_in_norm = rdin;
+        Pg.info.objective = obj;
         const long long t_end = wall_clock64();
-        P.info.setup_time = (double)(t_solve - t_begin) * 1e-8;          // scaling + warm start + initialize_mu of this item
-        P.info.solve_time = (double)(t_end - t_solve) * 1e-8;
-        P.info.run_time = P.info.setup_time + P.info.solve_time;
-        small_status(P.info, status);
-        P.newton_passes = newton; P.factor_count = nfactor; (void)nrestore;
+        Pg.info.setup_time = (double)(t_solve - t_begin) * 1e-8;          // scaling + warm start + initialize_mu of this item
+        Pg.info.solve_time = (double)(t_end - t_solve) * 1e-8;
+        Pg.info.run_time = Pg.info.setup_time + Pg.info.solve_time;
+        small_status(Pg.info, status);
+        Pg.newton_passes = newton; Pg.factor_count = nfactor; (void)nrestore;
     }
 }
 
@@ -972,7 +1095,7 @@ static int slot_finish(SmallSlot &S) {
         SHIP(hipMemcpy(hpf.data(), S.dprof, hpf.size() * sizeof(long long), hipMemcpyDeviceToHost));
         long best = 0; long long bt = -1;
         for (long i = 0; i < count; i++) { long long t = 0; for (int k = 0; k < PH_COUNT; k++) t += hpf[(size_t)i * PH_COUNT + k]; if (t > bt) { bt = t; best = i; } }
-        static const char *nm[PH_COUNT] = {"resid", "outer", "prep", "assemble", "factor", "solve", "spmv", "linesearch", "update"};
+        static const char *nm[PH_COUNT] = {"resid", "outer", "prep", "assemble", "factor", "solve", "spmv", "linesearch", "update", "(ls:dots", "ls:sort", "ls:jsum", "ls:walk)"};
         fprintf(stderr, "[qpdo_small prof] item %ld, %ld passes, ticks(100MHz):", best, (long)S.hp[(size_t)best].info.iterations);
         for (int k = 0; k < PH_COUNT; k++) fprintf(stderr, " %s=%.1fms", nm[k], hpf[(size_t)best * PH_COUNT + k] * 1e-5);
         fprintf(stderr, "\n");
