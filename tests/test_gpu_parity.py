@@ -379,6 +379,8 @@ def test_production_size_matches_oracle_fixture(name, gpu_required, monkeypatch)
         #                               and its reported norms belong to the start of the last pass, not to the final iterate)
         assert abs(rp - gi["res_prim_norm"]) <= 1e-9 and abs(rd - gi["res_dual_norm"]) <= 1e-9
         assert rp <= 1e-6 and rd <= 1e-6
+        # north star: "final KKT residual within 1e-10" of the reference's (here: the oracle's record of the same solve)
+        assert abs(gi["res_prim_norm"] - oi["res_prim_norm"]) <= KKT_ATOL and abs(gi["res_dual_norm"] - oi["res_dual_norm"]) <= KKT_ATOL
         Ax = p["A"] @ r["x"]
         inside = (Ax > p["l"] + 1e-5) & (Ax < p["u"] - 1e-5)
         assert np.abs(r["y"][inside]).max() <= 1e-5
