@@ -57,9 +57,9 @@ def test_row_partitioned_c4_matches_fixture(gpu_required):
     """BASELINE.json configs[3] at FULL size in its row-partitioned form (reference loop
     src/qpdo.c:343-449): n=1e5, m=2e5, 1 % fill through the partitioned code path -- unfused epilogues behind every
     exchange, partitioned k-vectors in the Schur-complement mode, every collective through ncclAllReduce on the solver's
-    stream (forced single-rank communicator: the one GPU of the box) -- against the oracle's record of the first 40 passes
-    (tests/golden/big_C4_first40.npz; its first 16 passes are big_C4_first16's): per-pass integers identical, tau / norms /
-    iterate after 40 passes within the PCG tolerances, one collective per inner iteration."""
+    stream (forced single-rank communicator: the one GPU of the box) -- against the oracle's record of the WHOLE solve
+    (tests/golden/big_C4_full.npz: 65 passes, 9 outer updates; big_C4_first40.npz if that file is absent): status and counts
+    identical, per-pass integers identical, tau / norms / final iterate within the PCG tolerances, one collective per inner iteration."""
     code = r"""
 import json, os, sys
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
@@ -68,7 +68,8 @@ os.environ["QPDO_DEVICE"] = "0"
 import numpy as np
 from helpers import assert_same_trace, trace_from_npz, close_vec, ITERATE_RTOL_PCG
 from qpdo_amd import problems, solver
-z = np.load(os.path.join(%r, "tests", "golden", "big_C4_first40.npz"))
+gold = os.path.join(%r, "tests", "golden")
+z = np.load(os.path.join(gold, "big_C4_full.npz" if os.path.exists(os.path.join(gold, "big_C4_full.npz")) else "big_C4_first40.npz"))
 meta = json.loads(str(z["meta"]))
 assert solver.dist_config(0, 1, mode="rccl", force=True) == 0
 p = problems.config_qp("C4", 0)

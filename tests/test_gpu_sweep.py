@@ -118,6 +118,26 @@ def test_fused_batch_sweep_is_bit_identical(gpu_required):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("n,m,dens,neq", [(60, 700, 0.1, 50), (100, 1000, 0.05, 0), (30, 1024, 0.2, 10), (250, 513, 0.03, 100), (40, 257, 0.2, 0), (8, 129, 0.5, 2)])
+def test_fused_batch_is_bit_identical_at_the_breakpoint_counts_that_change_the_sort_layout(n, m, dens, neq, gpu_required):
+    """The breakpoint sort of the fused kernel holds 1, 2 or 4 elements per thread (2m <= 512, <= 1024, <= 2048) and its one-lane sums are
+    folded by a wave 64 elements at a time: instances on both sides of every layout change (the sweep above stays below m = 320), three
+    seeds each, must carry the oracle's bits."""
+    probs = [problems.random_qp(4400 + 7 * k + m, n, m, dens, neq) for k in range(3)]
+    res, failed = solver.solve_batch(probs, verbose=0, max_iter=400)
+    assert failed == 0
+    for p, r in zip(probs, res):
+        o = ob.OracleSolver(p, ob.default_settings(max_iter=400))
+        ro = o.solve()
+        oi = dict(ro["info"])
+        o.close()
+        gi = r["info"]
+        assert (gi["status_val"], gi["iterations"], gi["oterations"]) == (oi["status_val"], oi["iterations"], oi["oterations"])
+        if oi["status_val"] not in (-3, -4):
+            assert np.array_equal(r["x"], ro["x"]) and np.array_equal(r["y"], ro["y"]) and gi["objective"] == oi["objective"]
+            assert gi["res_prim_norm"] == oi["res_prim_norm"] and gi["res_dual_norm"] == oi["res_dual_norm"]
+
+
 def test_streamed_overlapping_batches_are_bit_identical(gpu_required):
     """BASELINE.json configs[2] "streamed": three batches in flight at once on a batch stream (qpdo_amd_batch_stream_*) -- the
     same 120 varied instances split 50 / 40 / 30, the first with max_iter large enough that its slow items are still running
