@@ -118,6 +118,35 @@ def test_fused_batch_sweep_is_bit_identical(gpu_required):
     assert not bad, bad
 
 
+def test_batch_stream_api_edges(gpu_required, capfd):
+    """qpdo_amd_batch_stream_*: an unknown or already collected ticket is an error (not a hang), an item that does not fit the fused
+    kernel or invalid settings are refused at submit, a stream destroyed with a batch still in flight completes it first, and a slot
+    becomes free again once its ticket has been waited for"""
+    import ctypes as C
+    L = solver.lib()
+    probs = [problems.config_qp("C3", i) for i in range(8)]
+    B = solver.Batch(probs)
+    st = solver.BatchStream(depth=1)
+    t = st.submit(B, verbose=0, max_iter=50)
+    ks = C.c_double(0.0)
+    assert L.qpdo_amd_batch_stream_wait(st._h, C.c_long(t + 5), C.byref(ks)) == -1          # unknown ticket
+    res, _ = st.wait(t)
+    assert len(res) == 8 and all(r["info"]["iterations"] > 0 for r in res)
+    assert L.qpdo_amd_batch_stream_wait(st._h, C.c_long(t), C.byref(ks)) == -1              # already collected
+    t2 = st.submit(B, verbose=0, max_iter=50)                                               # the slot is free again
+    assert t2 == t + 1
+    st.close()                                                                              # in flight: destroy completes it
+    assert all(np.isfinite(x).all() for x, _ in B.outs)
+    st = solver.BatchStream(depth=2)
+    with pytest.raises(RuntimeError):
+        st.submit(B, verbose=0, rho=2.0)                                                    # invalid settings
+    big = solver.Batch([problems.random_qp(5, 1100, 40, 0.01)])                             # n > 1024: not for the fused kernel
+    with pytest.raises(RuntimeError):
+        st.submit(big, verbose=0)
+    st.close()
+    capfd.readouterr()
+
+
 @pytest.mark.parametrize("n,m,dens,neq", [(60, 700, 0.1, 50), (100, 1000, 0.05, 0), (30, 1024, 0.2, 10), (250, 513, 0.03, 100), (40, 257, 0.2, 0), (8, 129, 0.5, 2)])
 def test_fused_batch_is_bit_identical_at_the_breakpoint_counts_that_change_the_sort_layout(n, m, dens, neq, gpu_required):
     """The breakpoint sort of the fused kernel holds 1, 2 or 4 elements per thread (2m <= 512, <= 1024, <= 2048) and its one-lane sums are

@@ -17,3 +17,4 @@ print("integers identical", ints, "max tau dev %.2e" % dtau, "max norm dev (abs)
 print("|x-xo|inf %.2e |y-yo|inf %.2e" % (np.abs(r["x"] - z["x"]).max(), np.abs(r["y"] - z["y"]).max()), "objective", r["info"]["objective"], meta["info"]["objective"])
 print("KKT", r["info"]["res_prim_norm"], r["info"]["res_dual_norm"], "oracle", meta["info"]["res_prim_norm"], meta["info"]["res_dual_norm"])
 print("device lin iters", r["stats"]["lin_iters"], "oracle CG iterations", meta["oracle_lin_iters"], "oracle seconds", meta["oracle_seconds"])
+print("per pass (kind, n_active, lin_iters):", [(int(t["kind"]), int(t["n_active"]), int(t["lin_iters"])) for t in got])
