@@ -217,6 +217,24 @@ def test_solve_is_reproducible_run_to_run(gpu_required):
     assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["y"], b["y"])
 
 
+def test_deferred_step_read_back_changes_no_bit(gpu_required, monkeypatch):
+    """One host synchronisation per loop pass (the Newton step's read-back rides on the next residual read; round 3) against two
+    (QPDO_DEFER_STEP=0): the same kernels in the same order, so the same bits -- solution, counts, and every field of the trace,
+    including the step length that arrives one read later; also when the solve is cut off right after a Newton step (max_iter)."""
+    for prob, st in ((problems.random_qp(41, 400, 800, 0.03), {}), (problems.config_qp("C1"), dict(max_iter=200)),
+                     (problems.config_qp("C3"), dict(max_iter=7)), (problems.infeasibility_kat("dual_infeasible"), dict(max_iter=100))):
+        monkeypatch.setenv("QPDO_DEFER_STEP", "0")
+        a = solver.solve_problem(prob, verbose=0, **st)
+        monkeypatch.setenv("QPDO_DEFER_STEP", "1")
+        b = solver.solve_problem(prob, verbose=0, **st)
+        assert (a["info"]["status_val"], a["info"]["iterations"], a["info"]["oterations"]) == (b["info"]["status_val"], b["info"]["iterations"], b["info"]["oterations"])
+        assert np.array_equal(a["x"], b["x"], equal_nan=True) and np.array_equal(a["y"], b["y"], equal_nan=True)
+        assert np.array_equal(a["dual_inf_cert"], b["dual_inf_cert"], equal_nan=True)
+        assert len(a["trace"]) == len(b["trace"])
+        for ta, tb in zip(a["trace"], b["trace"]):
+            assert all(ta[k] == tb[k] for k in ta), (ta, tb)
+
+
 def test_max_iter_and_max_time_statuses(gpu_required):
     p = problems.config_qp("C1")
     r = solver.solve_problem(p, verbose=0, max_iter=3)
