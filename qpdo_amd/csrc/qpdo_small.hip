@@ -50,6 +50,7 @@ struct SmallQP {
     double *mv;                              // m-vector workspace (MV_COUNT * m)
     double *lsv;                             // 2 * (2m): ls_delta, ls_alpha
     int *iv;                                 // 3 * m ints: active, active_old, changed
+    int *tpos;                               // nnz(A) ints: for entry q of CSR(A') (column j, row r) the slot of column j in row r of CSR(A)
     double *K;                               // n * n, column-major, lower
     double c_const;
     // results
@@ -199,27 +200,40 @@ struct KView {
     __device__ __forceinline__ size_t off(int j) const { return packed ? (size_t)j * n - (size_t)j * (j + 1) / 2 : (size_t)j * n; }
     __device__ __forceinline__ double &at(int i, int j) const { return K[off(j) + i]; }
 };
-// assembly in the oracle's order: Q first, then rows r of A ascending (all threads share one row: every (i,j)
-// target of a row is distinct, rows are separated by a barrier), sigma_f last
+// Assembly in the oracle's order -- Q first, then the rows r of A ascending, sigma_f last -- WITHOUT a barrier per row: the
+// contributions to one entry K(i,j) must be added in ascending r, and they are when ONE thread owns the entry for the whole row loop.
+// Thread (j, part) owns the entries (i, j) with i % 4 == part (ownership by TARGET, not by position in a row): it walks column j of A (= row j
+// of CSR(A'), rows ascending), and for every weighted row r adds (A_rj d_r) A_ri for the columns i >= j of that row it is responsible
+// for -- the products and the order of the former row-by-row loop (one barrier per weighted row: ~120 of them, 16 % of a pass), so
+// the same bits.  tpos[q] is the slot of column j inside row r of CSR(A) for entry q of CSR(A') (built once per item, below).
+__device__ void small_build_tpos(SmallQP &P) {
+    FOR_T(j, P.n) for (int q = P.Trp[j]; q < P.Trp[j + 1]; q++) {
+        const int r = P.Tci[q];
+        int lo = P.Arp[r], hi = P.Arp[r + 1] - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.Aci[mid] < j) lo = mid + 1; else hi = mid; }
+        P.tpos[q] = lo;
+    }
+}
 __device__ void small_assemble(SmallQP &P, const KView &kv, const double *dw, double sigma_f, const int *rp_s, double *d_s) {
     const int n = P.n, m = P.m;
     const size_t tot = kv.packed ? (size_t)n * (n + 1) / 2 : (size_t)n * n;
     for (size_t i = threadIdx.x; i < tot; i += blockDim.x) kv.K[i] = 0.0;
-    FOR_T(r, m) d_s[r] = dw[r];                    // weights of this pass into LDS: the row loop below reads them uniformly
+    FOR_T(r, m) d_s[r] = dw[r];                    // weights of this pass into LDS
     SYNC;
     FOR_T(r, n) for (int k = P.Qrp[r]; k < P.Qrp[r + 1]; k++) { const int cc = P.Qci[k]; if (r >= cc) kv.at(r, cc) += P.Qval[k]; }
     SYNC;
-    for (int r = 0; r < m; r++) {
-        const double wgt = d_s[r];
-        if (wgt == 0.0) continue;
-        const int b = rp_s[r], len = rp_s[r + 1] - b;
-        // pairs (a <= bb) of the row's entries: columns ascending, so Aci[b+bb] >= Aci[b+a]
-        for (int pidx = threadIdx.x; pidx < len * len; pidx += blockDim.x) {
-            const int a = pidx / len, bb = pidx % len;
-            if (bb >= a) { const double vj = P.Aval[b + a] * wgt; kv.at(P.Aci[b + bb], P.Aci[b + a]) += vj * P.Aval[b + bb]; }
+    for (int jp = threadIdx.x; jp < 4 * n; jp += blockDim.x) {
+        const int j = jp >> 2, part = jp & 3;
+        for (int q = P.Trp[j]; q < P.Trp[j + 1]; q++) {
+            const int r = P.Tci[q];
+            const double wgt = d_s[r];
+            if (wgt == 0.0) continue;
+            const int s = P.tpos[q], e = rp_s[r + 1];
+            const double vj = P.Aval[s] * wgt;
+            for (int bb = s; bb < e; bb++) { const int i = P.Aci[bb]; if ((i & 3) == part) kv.at(i, j) += vj * P.Aval[bb]; }
         }
-        SYNC;
     }
+    SYNC;
     FOR_T(j, n) kv.at(j, j) += sigma_f;
     SYNC;
 }
@@ -519,7 +533,7 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
     P.n = __builtin_amdgcn_readfirstlane(Pg.n); P.m = __builtin_amdgcn_readfirstlane(Pg.m);
 #define UNI_PTR(f) P.f = uni_ptr(Pg.f)
     UNI_PTR(Arp); UNI_PTR(Aci); UNI_PTR(Aval); UNI_PTR(Trp); UNI_PTR(Tci); UNI_PTR(Tval); UNI_PTR(Qrp); UNI_PTR(Qci); UNI_PTR(Qval);
-    UNI_PTR(q); UNI_PTR(l); UNI_PTR(u); UNI_PTR(x0); UNI_PTR(y0); UNI_PTR(nv); UNI_PTR(mv); UNI_PTR(lsv); UNI_PTR(iv); UNI_PTR(K);
+    UNI_PTR(q); UNI_PTR(l); UNI_PTR(u); UNI_PTR(x0); UNI_PTR(y0); UNI_PTR(nv); UNI_PTR(mv); UNI_PTR(lsv); UNI_PTR(iv); UNI_PTR(tpos); UNI_PTR(K);
     UNI_PTR(sol_x); UNI_PTR(sol_y); UNI_PTR(cert_dx); UNI_PTR(cert_dy); UNI_PTR(prof);
 #undef UNI_PTR
     P.c_const = Pg.c_const;
@@ -553,6 +567,7 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
     double sc_c = 1.0, sc_cinv = 1.0;
 
     FOR_T(r, m + 1) rp_s[r] = P.Arp[r];
+    small_build_tpos(P);
     // ---- setup: workspace zero + scaling (qpdo.c:49-212) ----
     FOR_T(i, NV_COUNT * n) P.nv[i] = 0.0;
     FOR_T(i, MV_COUNT * m) P.mv[i] = 0.0;
@@ -916,7 +931,7 @@ static void sym_full32(const cholmod_sparse *Q, HostCsr32 &o) {            // fu
 // (qdev_small_stream_*) owns `depth` slots, so that batch i+1 is packed, uploaded and started while the slowest workgroups of
 // batch i still run: a launch is as slow as its slowest item (an instance that never reaches eps runs max_iter passes on one
 // workgroup), and with one batch at a time the other CUs idle behind it.
-struct Lay { size_t Arp, Aci, Aval, Trp, Tci, Tval, Qrp, Qci, Qval, q, l, u, x0, y0, nv, mv, lsv, iv, K, solx, soly, dx, dy; HostCsr32 A, T, Q; };
+struct Lay { size_t Arp, Aci, Aval, Trp, Tci, Tval, Qrp, Qci, Qval, q, l, u, x0, y0, nv, mv, lsv, iv, tpos, K, solx, soly, dx, dy; HostCsr32 A, T, Q; };
 struct SmallSlot {
     int device = -1;
     hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1004,7 +1019,7 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
         const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
         const size_t n = d->n, m = d->m;
         L.nv = reserve((size_t)NV_COUNT * n * 8); L.mv = reserve((size_t)MV_COUNT * m * 8 + 8); L.lsv = reserve(4 * m * 8 + 8);
-        L.iv = reserve(3 * m * 4 + 4); L.K = reserve(n * n * 8);
+        L.iv = reserve(3 * m * 4 + 4); L.tpos = reserve(L.A.ci.size() * 4 + 4); L.K = reserve(n * n * 8);
     }
     char *harena = nullptr, *dbase = nullptr; SmallQP *hp = nullptr;
     SHIP(hipSetDevice(device));
@@ -1044,7 +1059,7 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
         p.Qrp = (const int *)(dbase + L.Qrp); p.Qci = (const int *)(dbase + L.Qci); p.Qval = (double *)(dbase + L.Qval);
         p.q = (double *)(dbase + L.q); p.l = (double *)(dbase + L.l); p.u = (double *)(dbase + L.u);
         p.x0 = items[i].x0 ? (const double *)(dbase + L.x0) : nullptr; p.y0 = items[i].y0 ? (const double *)(dbase + L.y0) : nullptr;
-        p.nv = (double *)(dbase + L.nv); p.mv = (double *)(dbase + L.mv); p.lsv = (double *)(dbase + L.lsv); p.iv = (int *)(dbase + L.iv);
+        p.nv = (double *)(dbase + L.nv); p.mv = (double *)(dbase + L.mv); p.lsv = (double *)(dbase + L.lsv); p.iv = (int *)(dbase + L.iv); p.tpos = (int *)(dbase + L.tpos);
         p.K = (double *)(dbase + L.K);
         p.sol_x = (double *)(dbase + L.solx); p.sol_y = (double *)(dbase + L.soly); p.cert_dx = (double *)(dbase + L.dx); p.cert_dy = (double *)(dbase + L.dy);
     }
