@@ -202,10 +202,11 @@ struct KView {
 };
 // Assembly in the oracle's order -- Q first, then the rows r of A ascending, sigma_f last -- WITHOUT a barrier per row: the
 // contributions to one entry K(i,j) must be added in ascending r, and they are when ONE thread owns the entry for the whole row loop.
-// Thread (j, part) owns the entries (i, j) with i % 4 == part (ownership by TARGET, not by position in a row): it walks column j of A (= row j
+// Column j belongs to the four ADJACENT lanes 4j..4j+3 of one wave (lane `part` takes every fourth entry of a row's tail): they walk column j of A (= row j
 // of CSR(A'), rows ascending), and for every weighted row r adds (A_rj d_r) A_ri for the columns i >= j of that row it is responsible
 // for -- the products and the order of the former row-by-row loop (one barrier per weighted row: ~120 of them, 16 % of a pass), so
-// the same bits.  tpos[q] is the slot of column j inside row r of CSR(A) for entry q of CSR(A') (built once per item, below).
+// the same bits.  (An entry K(i,j) may be touched by different lanes of the quartet in different rows; they are lanes of ONE wave
+// running the same loop in lockstep, and a wave's LDS operations execute in program order, so the additions still land in row order.)  tpos[q] is the slot of column j inside row r of CSR(A) for entry q of CSR(A') (built once per item, below).
 __device__ void small_build_tpos(SmallQP &P) {
     FOR_T(j, P.n) for (int q = P.Trp[j]; q < P.Trp[j + 1]; q++) {
         const int r = P.Tci[q];
@@ -230,7 +231,7 @@ __device__ void small_assemble(SmallQP &P, const KView &kv, const double *dw, do
             if (wgt == 0.0) continue;
             const int s = P.tpos[q], e = rp_s[r + 1];
             const double vj = P.Aval[s] * wgt;
-            for (int bb = s; bb < e; bb++) { const int i = P.Aci[bb]; if ((i & 3) == part) kv.at(i, j) += vj * P.Aval[bb]; }
+            for (int bb = s + part; bb < e; bb += 4) kv.at(P.Aci[bb], j) += vj * P.Aval[bb];
         }
     }
     SYNC;
