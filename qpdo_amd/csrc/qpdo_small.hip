@@ -244,7 +244,7 @@ __device__ void small_assemble(SmallQP &P, const KView &kv, const double *dw, do
 // pointer provenance visible to the compiler (ds_read instead of flat loads).
 template <bool PACKED>
 __device__ __forceinline__ void small_factor_t(int n, double *__restrict__ K, double *__restrict__ lcol, double *__restrict__ tcol,
-                                               double *__restrict__ lcol1, double *__restrict__ tcol1) {
+                                               double *__restrict__ lcol1, double *__restrict__ tcol1, int k_start = 0, int offk_start = 0) {
     // Right-looking (outer-product) LDL'.  Element (i,j) receives  -= l_ik * (l_jk d_k)  at step k, i.e. the same
     // subtractions in the same ascending-k order as the left-looking reference loop - bit-identical results - but
     // every step updates the whole trailing triangle, so all waves of the workgroup have work.
@@ -254,8 +254,8 @@ __device__ __forceinline__ void small_factor_t(int n, double *__restrict__ K, do
     // l_{k+1,k} and d_{k+1} recomputed by every thread from the same LDS values, so the same bits -- and the trailing update then
     // makes the subtractions of step k and of step k+1 one after the other.
     const int li = threadIdx.x & 63, wj = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int offk = 0;                                   // off(k)
-    int k = 0;
+    int offk = offk_start;                          // off(k)
+    int k = k_start;
     for (; k + 1 < n; k += 2) {
         const int offk1 = offk + (PACKED ? n - k - 1 : n);            // off(k+1)
         const double dk = K[offk + k], inv = 1.0 / dk;
@@ -299,6 +299,75 @@ __device__ __forceinline__ void small_factor_t(int n, double *__restrict__ K, do
     if (k < n) {                                    // odd n: the last column has nothing below it
         SYNC;
     }
+}
+// FOUR columns per barrier pair (round 3).  Every thread factors the leading 4 x 4 block itself, from the same LDS values and with the
+// operations the two-column steps k, k+2 would have made, and carries its rows through all four columns; the trailing update then
+// makes the subtractions of steps k .. k+3 one after the other.  Per element: the same subtractions in the same ascending-k order
+// -- the same bits as the two-column version (and as the left-looking reference loop) -- with half the barriers and half the
+// read-modify-write traffic on K.  F: 8n doubles of LDS (l and l*d of the four columns).  The last n mod 4 columns go through the
+// two-column code.
+template <bool PACKED>
+__device__ __forceinline__ void small_factor4_t(int n, double *__restrict__ K, double *__restrict__ F) {
+    double *L0 = F, *L1 = F + n, *L2 = F + 2 * (size_t)n, *L3 = F + 3 * (size_t)n;
+    double *T0 = F + 4 * (size_t)n, *T1 = F + 5 * (size_t)n, *T2 = F + 6 * (size_t)n, *T3 = F + 7 * (size_t)n;
+    const int li = threadIdx.x & 63, wj = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int off0 = 0, k = 0;
+    for (; k + 3 < n; k += 4) {
+        const int off1 = off0 + (PACKED ? n - k - 1 : n), off2 = off1 + (PACKED ? n - k - 2 : n), off3 = off2 + (PACKED ? n - k - 3 : n);
+        const double d0 = K[off0 + k], inv0 = 1.0 / d0;
+        const double l10 = K[off0 + k + 1] * inv0, l20 = K[off0 + k + 2] * inv0, l30 = K[off0 + k + 3] * inv0;
+        const double t10 = l10 * d0, t20 = l20 * d0, t30 = l30 * d0;
+        const double d1 = K[off1 + k + 1] - l10 * t10, inv1 = 1.0 / d1;
+        const double l21 = (K[off1 + k + 2] - l20 * t10) * inv1, l31 = (K[off1 + k + 3] - l30 * t10) * inv1;
+        const double t21 = l21 * d1, t31 = l31 * d1;
+        const double d2 = (K[off2 + k + 2] - l20 * t20) - l21 * t21, inv2 = 1.0 / d2;
+        const double l32 = ((K[off2 + k + 3] - l30 * t20) - l31 * t21) * inv2, t32 = l32 * d2;
+        const double d3 = ((K[off3 + k + 3] - l30 * t30) - l31 * t31) - l32 * t32, inv3 = 1.0 / d3;
+        for (int i = k + 4 + (int)threadIdx.x; i < n; i += blockDim.x) {
+            const double l0 = K[off0 + i] * inv0;
+            const double v1 = K[off1 + i] - l0 * t10;
+            const double l1 = v1 * inv1;
+            const double v2 = (K[off2 + i] - l0 * t20) - l1 * t21;
+            const double l2 = v2 * inv2;
+            const double v3 = ((K[off3 + i] - l0 * t30) - l1 * t31) - l2 * t32;
+            const double l3 = v3 * inv3;
+            K[off0 + i] = l0; K[off1 + i] = l1; K[off2 + i] = l2; K[off3 + i] = l3;
+            L0[i] = l0; L1[i] = l1; L2[i] = l2; L3[i] = l3;
+            T0[i] = l0 * d0; T1[i] = l1 * d1; T2[i] = l2 * d2; T3[i] = l3 * d3;
+        }
+        SYNC;
+        if (threadIdx.x == 0) {                       // (inputs of every thread above: overwritten after the barrier)
+            K[off0 + k + 1] = l10; K[off0 + k + 2] = l20; K[off0 + k + 3] = l30;
+            K[off1 + k + 1] = d1;  K[off1 + k + 2] = l21; K[off1 + k + 3] = l31;
+            K[off2 + k + 2] = d2;  K[off2 + k + 3] = l32; K[off3 + k + 3] = d3;
+        }
+        for (int j0 = k + 4 + wj; j0 < n; j0 += 2 * nw) {
+            int jj[2], off[2]; double tj[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                jj[u] = j0 + u * nw;
+                const int jc = jj[u] < n ? jj[u] : n - 1;
+                tj[u][0] = T0[jc]; tj[u][1] = T1[jc]; tj[u][2] = T2[jc]; tj[u][3] = T3[jc];
+                off[u] = PACKED ? jc * n - (jc * (jc + 1)) / 2 : jc * n;
+            }
+            for (int i = k + 4 + li; i < n; i += 64) {
+                const double a0 = L0[i], a1 = L1[i], a2 = L2[i], a3 = L3[i];
+                double v[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) v[u] = (jj[u] < n && i >= jj[u]) ? K[off[u] + i] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 2; u++) if (jj[u] < n && i >= jj[u]) {
+                    double w = v[u] - a0 * tj[u][0];
+                    w = w - a1 * tj[u][1];
+                    w = w - a2 * tj[u][2];
+                    K[off[u] + i] = w - a3 * tj[u][3];
+                }
+            }
+        }
+        SYNC;
+        off0 = off3 + (PACKED ? n - k - 4 : n);
+    }
+    if (k < n) small_factor_t<PACKED>(n, K, L0, T0, L1, T1, k, off0);
 }
 // x lives in LDS (xs) for the duration of the solve.  Two columns per barrier, as in the factorization: every thread applies step j
 // to entry j+1 itself (x_{j+1} = xs[j+1] - L(j+1,j) x_j, the subtraction the column sweep would have made), then each entry receives
@@ -519,7 +588,7 @@ __device__ __forceinline__ T *uni_ptr(T *p) {
 // ---- the whole solve of one QP by one workgroup ----------------------------------------------------------
 __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, int count, QPDOSettings st, int klds_ok) {
     __shared__ double sm[32];
-    // dynamic LDS: [xs: n][colbuf: n][tk: 2n][gbuf][d_s: m][rp_s: m+1][U], U = one region shared by the packed factor K
+    // dynamic LDS: [xs: n][colbuf: n][tk: 2n][4n more for the four-column factorization][gbuf][d_s: m][rp_s: m+1][U], U = one region shared by the packed factor K
     // (if it fits) and the linesearch scratch (delta, alpha, sort keys, sort indices, flags).  The linesearch of a
     // pass runs after the pass's solve, so it may overwrite K: the factor is then rebuilt in the next pass instead
     // of being reused when the weights did not change -- the same bits, a little more work -- and the workgroup needs
@@ -554,7 +623,7 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
            *res_prim_old = V[MV_RPOLD], *res_prim_in = V[MV_RPI], *dy = V[MV_DY], *Adx = V[MV_ADX], *dw = V[MV_DW], *E = V[MV_E],
            *Einv = V[MV_EINV], *ats = V[MV_ATS], *tm = V[MV_T], *dwf = V[MV_DWF];
     int *active = P.iv, *active_old = P.iv + m, *changed = P.iv + 2 * m;
-    double *xs = dyn, *colbuf = dyn + n, *tk = dyn + 2 * (size_t)n, *gbuf = dyn + 4 * (size_t)n;
+    double *xs = dyn, *colbuf = dyn + n, *tk = dyn + 2 * (size_t)n, *gbuf = dyn + 8 * (size_t)n;      // dyn .. dyn + 8n: l and l*d of four columns during a factorization
     double *d_s = gbuf + (((size_t)(n > m ? n : m) / 4 + 4 + 1) & ~(size_t)1);
     int *rp_s = (int *)(d_s + m);
     double *Klds = (double *)(rp_s + (((size_t)m + 1 + 3) & ~(size_t)3));          // start of U
@@ -796,7 +865,7 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
                 FOR_T(i, m) dwf[i] = dw[i];
                 fact_sigma_f = sigma_f; have_fact = 1;
                 small_assemble(P, kv, dw, sigma_f, rp_s, d_s); PH(PH_ASM);
-                if (klds_ok) small_factor_t<true>(n, Klds, colbuf, tk, xs, tk + n); else small_factor_t<false>(n, P.K, colbuf, tk, xs, tk + n);
+                if (klds_ok) small_factor4_t<true>(n, Klds, dyn); else small_factor4_t<false>(n, P.K, dyn);
                 PH(PH_FACTOR); factor_valid = 1; nfactor++;
                 // The factor shares its LDS region with the linesearch scratch, so it does not survive the pass.  A copy in the
                 // item's global K buffer (58 KB at n = 120, L2-resident) lets the next passes RESTORE it while (sigma_f, d) stay
@@ -1077,7 +1146,7 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
     {
         size_t nmax = 1, mmax = 0;
         for (long i = 0; i < count; i++) { if (items[i].data->n > nmax) nmax = items[i].data->n; if (items[i].data->m > mmax) mmax = items[i].data->m; }
-        size_t lds = 4 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
+        size_t lds = 8 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
         const size_t kbytes = nmax * (nmax + 1) / 2 * 8;
         size_t np2 = 1; while (np2 < 2 * mmax) np2 <<= 1;
         const size_t lsbytes = 2 * mmax * (8 + 8) + np2 * (8 + 4) + ((2 * mmax + 15) & ~(size_t)15);   // delta, alpha, keys, indices, flags
