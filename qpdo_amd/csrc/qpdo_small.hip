@@ -536,12 +536,36 @@ __device__ __attribute__((noinline)) double small_linesearch(SmallQP &P, double 
 #define PHL(k) do { if (P.prof && threadIdx.x == 0) { const long long t_ = wall_clock64(); P.prof[k] += t_ - tls; tls = t_; } } while (0)
     double *dy = V[MV_DY], *mu = V[MV_MU], *isq = V[MV_ISQ], *w = V[MV_W], *y = V[MV_Y], *Adx = V[MV_ADX];
     FOR_T(i, m) { double s = dy[i] * mu[i]; s = s * 0.5; tm[i] = s; }
-    double eta = dot_seq(dy, tm, m, sm, gbuf);
-    eta += dot_seq(P.nv + (size_t)NV_DX * n, P.nv + (size_t)NV_QDX * n, n, sm, gbuf);
-    eta *= 0.5;
-    double beta = dot_seq(y, tm, m, sm, gbuf);
-    beta += dot_seq(P.nv + (size_t)NV_DX * n, P.nv + (size_t)NV_DF * n, n, sm, gbuf);
-    beta *= 0.5;
+    // The four dot products of linesearch.c:19-25 together (round 3; were four dot_seq calls of three barriers each): all threads form
+    // the bracketed 4-groups of all four (lin_alg.c:59-71) into the union region, which nothing uses at this point, then lanes 0..3 of
+    // wave 0 each add the groups and the tail of ONE product in order -- four one-lane loops side by side in SIMD.
+    double eta, beta;
+    {
+        const double *dxv = P.nv + (size_t)NV_DX * n, *qdx = P.nv + (size_t)NV_QDX * n, *dfv = P.nv + (size_t)NV_DF * n;
+        const int ngm = m >> 2, cm = ngm + (m - 4 * ngm), ngn = n >> 2, cn = ngn + (n - 4 * ngn);
+        double *G0 = ls_delta, *G1 = G0 + cm, *G2 = G1 + cn, *G3 = G2 + cm;        // (2 cm + 2 cn doubles: the host sizes the union region for them)
+        SYNC;
+        FOR_T(g, ngm) { const int i = 4 * g;
+            G0[g] = (dy[i] * tm[i] + dy[i + 1] * tm[i + 1] + dy[i + 2] * tm[i + 2] + dy[i + 3] * tm[i + 3]);
+            G2[g] = (y[i] * tm[i] + y[i + 1] * tm[i + 1] + y[i + 2] * tm[i + 2] + y[i + 3] * tm[i + 3]); }
+        FOR_T(t, m - 4 * ngm) { G0[ngm + t] = dy[4 * ngm + t] * tm[4 * ngm + t]; G2[ngm + t] = y[4 * ngm + t] * tm[4 * ngm + t]; }
+        FOR_T(g, ngn) { const int i = 4 * g;
+            G1[g] = (dxv[i] * qdx[i] + dxv[i + 1] * qdx[i + 1] + dxv[i + 2] * qdx[i + 2] + dxv[i + 3] * qdx[i + 3]);
+            G3[g] = (dxv[i] * dfv[i] + dxv[i + 1] * dfv[i + 1] + dxv[i + 2] * dfv[i + 2] + dxv[i + 3] * dfv[i + 3]); }
+        FOR_T(t, n - 4 * ngn) { G1[ngn + t] = dxv[4 * ngn + t] * qdx[4 * ngn + t]; G3[ngn + t] = dxv[4 * ngn + t] * dfv[4 * ngn + t]; }
+        SYNC;
+        if (threadIdx.x < 4) {
+            const double *G = threadIdx.x == 0 ? G0 : threadIdx.x == 1 ? G1 : threadIdx.x == 2 ? G2 : G3;
+            const int cnt = (threadIdx.x & 1) ? cn : cm;
+            double prod = 0.0;
+            for (int g = 0; g < cnt; g++) prod += G[g];
+            sm[24 + threadIdx.x] = prod;
+        }
+        SYNC;
+        eta = sm[24]; eta += sm[25]; eta *= 0.5;
+        beta = sm[26]; beta += sm[27]; beta *= 0.5;
+        SYNC;                                        // the group arrays live where delta / alpha are written next
+    }
     FOR_T(i, m) {
         double c0 = Adx[i] - tm[i]; c0 = c0 * isq[i];
         ls_delta[i + m] = c0; ls_delta[i] = c0 * -1.0;
@@ -578,18 +602,19 @@ __device__ __attribute__((noinline)) double small_linesearch(SmallQP &P, double 
     // J sums by wave 0: lane l takes element c + l; an element outside J contributes +0.0, which never changes a running sum that
     // starts at +0.0 (x + 0 = x for x != -0, and such a sum is never -0: (+0) + (-0) = +0 and an exact cancellation gives +0)
     double sa = 0.0, sb = 0.0; int nL = 0;
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
+    if (threadIdx.x < 128) {                       // wave 0: sum of delta^2 over J and the count of L; wave 1: sum of delta*alpha over J
+        const int lane = threadIdx.x & 63, second = threadIdx.x >> 6;
 #pragma nounroll
         for (int c = 0; c < M2; c += 64) {
             const int i = c + lane;
             const unsigned char f = i < M2 ? jflag[i] : 0;
             const double dl = i < M2 ? ls_delta[i] : 0.0, al = i < M2 ? ls_alpha[i] : 0.0;
-            const double va = (f & 2) ? dl * dl : 0.0, vb = (f & 2) ? dl * al : 0.0;
-            nL += __popcll(__ballot(f & 1));
+            const double v = (f & 2) ? (second ? dl * al : dl * dl) : 0.0;
+            if (!second) nL += __popcll(__ballot(f & 1));
 #pragma unroll
-            for (int l = 0; l < 64; l++) { sa += rl64(va, l); sb += rl64(vb, l); }
+            for (int l = 0; l < 64; l++) sa += rl64(v, l);
         }
+        if (threadIdx.x == 64) sm[28] = sa;         // (wave 1's fold is the delta*alpha sum)
     }
     PHL(PH_LS_JSUM);
     SYNC;                                             // everyone is done with the index-ordered arrays
@@ -600,6 +625,7 @@ __device__ __attribute__((noinline)) double small_linesearch(SmallQP &P, double 
     }
     SYNC;
     if (threadIdx.x == 0) {
+        sb = sm[28];
         double a = eta + sa, b = beta - sb, tau;
         if (nL == 0) tau = -b / a;
         else {
@@ -1223,7 +1249,8 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
         size_t lds = 8 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
         const size_t kbytes = nmax * (nmax + 1) / 2 * 8;
         size_t np2 = 1; while (np2 < 2 * mmax) np2 <<= 1;
-        const size_t lsbytes = 2 * mmax * (8 + 8) + np2 * (8 + 4) + ((2 * mmax + 15) & ~(size_t)15);   // delta, alpha, keys, indices, flags
+        size_t lsbytes = 2 * mmax * (8 + 8) + np2 * (8 + 4) + ((2 * mmax + 15) & ~(size_t)15);   // delta, alpha, keys, indices, flags
+        { const size_t gdots = 8 * (2 * (mmax / 4 + 4) + 2 * (nmax / 4 + 4)); if (gdots > lsbytes) lsbytes = gdots; }   // the group arrays of the four dot products live there too
         const size_t budget = 160 * 1024 - 1024;                // static LDS: reduction scratch only
         int klds_ok = (lds + (kbytes > lsbytes ? kbytes : lsbytes) <= budget) ? 1 : 0;
         if (const char *kg = getenv("QPDO_SMALL_K_GLOBAL")) { if (atoi(kg)) klds_ok = 0; }      // occupancy experiments
