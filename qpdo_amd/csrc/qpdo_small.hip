@@ -119,6 +119,32 @@ __device__ int blk_sum_int(int v, int *sm) {
     for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += sm[i];
     return t;
 }
+// four maxima / three integer sums with ONE pair of barriers (max and integer addition are exact and order independent)
+__device__ void blk_max4(double &a, double &b, double &c, double &d, double *sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double t = __shfl_down(a, o, 64); a = t > a ? t : a; t = __shfl_down(b, o, 64); b = t > b ? t : b;
+        t = __shfl_down(c, o, 64); c = t > c ? t : c; t = __shfl_down(d, o, 64); d = t > d ? t : d;
+    }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;     // nw <= 8: sm[0 .. 31]
+    SYNC;
+    if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[8 + w] = b; sm[16 + w] = c; sm[24 + w] = d; }
+    SYNC;
+    a = sm[0]; b = sm[8]; c = sm[16]; d = sm[24];
+    for (int i = 1; i < nw; i++) { a = sm[i] > a ? sm[i] : a; b = sm[8 + i] > b ? sm[8 + i] : b; c = sm[16 + i] > c ? sm[16 + i] : c; d = sm[24 + i] > d ? sm[24 + i] : d; }
+    SYNC;                                           // (sm is reused right away by the caller's next reduction)
+}
+__device__ void blk_sum_int3(int &a, int &b, int &c, int *sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); c += __shfl_down(c, o, 64); }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    SYNC;
+    if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[8 + w] = b; sm[16 + w] = c; }
+    SYNC;
+    a = 0; b = 0; c = 0;
+    for (int i = 0; i < nw; i++) { a += sm[i]; b += sm[8 + i]; c += sm[16 + i]; }
+    SYNC;
+}
 // inf-norm of a vector, or of a .* b when b != NULL (lin_alg.c:107-140: NaN never wins)
 __device__ double norm_inf(const double *a, const double *b, int n, double *sm) {
     double mx = 0.0;
@@ -803,10 +829,16 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
             df[j] = dfi; res_dual[j] = rd; res_dual_in[j] = dfi + aty;
         }
         SYNC;
-        rpn = norm_inf(res_prim, scaled ? Einv : nullptr, m, sm);
-        rdn = norm_inf(res_dual, scaled ? Dinv : nullptr, n, sm); if (scaled) rdn *= sc_cinv;
-        rpin = norm_inf(res_prim_in, scaled ? Einv : nullptr, m, sm);
-        rdin = norm_inf(res_dual_in, scaled ? Dinv : nullptr, n, sm); if (scaled) rdin *= sc_cinv;
+        {   // the four residual norms with one pair of barriers (were four reductions)
+            double m1 = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0;
+            FOR_T(i, m) { const double e = scaled ? Einv[i] : 1.0; const double a1 = s_abs(scaled ? res_prim[i] * e : res_prim[i]), a3 = s_abs(scaled ? res_prim_in[i] * e : res_prim_in[i]);
+                          m1 = a1 > m1 ? a1 : m1; m3 = a3 > m3 ? a3 : m3; }
+            FOR_T(j, n) { const double e = scaled ? Dinv[j] : 1.0; const double a2 = s_abs(scaled ? res_dual[j] * e : res_dual[j]), a4 = s_abs(scaled ? res_dual_in[j] * e : res_dual_in[j]);
+                          m2 = a2 > m2 ? a2 : m2; m4 = a4 > m4 ? a4 : m4; }
+            blk_max4(m1, m2, m3, m4, sm);
+            rpn = m1; rdn = m2; rpin = m3; rdin = m4;
+            if (scaled) { rdn *= sc_cinv; rdin *= sc_cinv; }
+        }
         if ((rpn > SM_INFTY) || (rdn > SM_INFTY)) { status = QPDO_NON_CVX; break; }
         if ((rpn <= st.eps_abs) && (rdn <= st.eps_abs)) { status = QPDO_SOLVED; break; }
         const int inner_opt = (rpin <= eps_in) && (rdin <= eps_in);
@@ -927,7 +959,7 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
                 const int act = (w[i] <= P.l[i]) || (w[i] >= P.u[i]);
                 active[i] = act; na += act; ne += (act && !active_old[i]); nl += (!act && active_old[i]);
             }
-            na = blk_sum_int(na, (int *)sm); ne = blk_sum_int(ne, (int *)sm); nl = blk_sum_int(nl, (int *)sm);
+            blk_sum_int3(na, ne, nl, (int *)sm);
             int branch;
             if ((reset_newton && na) || (ne + nl) > SM_MAX_RANK_UPDATE) { reset_newton = 0; branch = 0; }
             else if (na) branch = 1; else branch = 2;
