@@ -118,6 +118,33 @@ def test_fused_batch_sweep_is_bit_identical(gpu_required):
     assert not bad, bad
 
 
+def test_fused_batch_degenerate_shapes_are_bit_identical(gpu_required):
+    """m = 0 (no constraints), n = 1, a single constraint, a row without entries: the fused kernel's sort layouts, wave folds, quartet
+    assembly and one-wave solves at their smallest sizes, against the oracle bit for bit"""
+    import scipy.sparse as sp
+    probs = []
+    p = problems.random_qp(52, 80, 1, 0.1)
+    p["A"] = sp.csc_matrix((0, 80)); p["l"] = np.zeros(0); p["u"] = np.zeros(0); p["m"] = 0
+    probs.append(p)
+    probs.append(problems.random_qp(27, 1, 5, 1.0, 0))
+    probs.append(problems.random_qp(26, 64, 1, 0.2, 0))
+    probs.append(problems.random_qp(28, 65, 3, 0.2, 1))
+    q = problems.random_qp(29, 30, 12, 0.2, 0)
+    A = sp.lil_matrix(q["A"]); A[4, :] = 0.0; q["A"] = sp.csc_matrix(A); q["A"].eliminate_zeros()      # an empty row
+    probs.append(q)
+    res, failed = solver.solve_batch(probs, verbose=0, max_iter=500)
+    assert failed == 0
+    for p, r in zip(probs, res):
+        o = ob.OracleSolver(p, ob.default_settings(max_iter=500))
+        ro = o.solve()
+        oi = dict(ro["info"])
+        o.close()
+        gi = r["info"]
+        assert (gi["status_val"], gi["iterations"], gi["oterations"]) == (oi["status_val"], oi["iterations"], oi["oterations"]), (p["n"], p["m"])
+        if oi["status_val"] not in (-3, -4):
+            assert np.array_equal(r["x"], ro["x"]) and np.array_equal(r["y"], ro["y"]) and gi["objective"] == oi["objective"], (p["n"], p["m"])
+
+
 def test_batch_stream_api_edges(gpu_required, capfd):
     """qpdo_amd_batch_stream_*: an unknown or already collected ticket is an error (not a hang), an item that does not fit the fused
     kernel or invalid settings are refused at submit, a stream destroyed with a batch still in flight completes it first, and a slot
