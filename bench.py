@@ -13,6 +13,10 @@ ranks); `ms_per_step` = wall time per step (C4/C2: time-to-eps, inputs already i
 `time_to_eps_incl_setup_s` adds it, which is what the reference's info->run_time measures, src/qpdo.c:461-464).
 N > 1: independent QPs (different seeds) per rank / disjoint shards of the batch: no data-path collective ("weak");
 --partition rows: ONE QP with the rows of A partitioned over the ranks and RCCL all-reduces ("strong").
+Launching N > 1: either `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the driver's form: RANK /
+WORLD_SIZE come from the launcher) or the bare `python bench.py --gpus N ...`: with no RANK / WORLD_SIZE in the environment the script
+starts its N ranks itself (launch_ranks: before anything loads the library or touches HIP), relays rank 0's JSON line and the worst
+exit code; fewer than N visible GPUs, or a rank count that differs from --gpus, is an error, never a silently different n_gpus.
 
 Adds to the JSON line:
   roofline     -- HBM roofline of the dominant kernel: algorithmic bytes (12 nnz + 4(rows+1) + 8 rows + 8 cols) over the
@@ -23,6 +27,9 @@ Adds to the JSON line:
 import argparse
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -70,6 +77,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the informational C2 / C3-batch measurements")
     ap.add_argument("--no-mixed-extra", action="store_true", help="skip the informational fp32-inner-preconditioner solve")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rank plumbing only: rendezvous, barrier and the two reductions of the timed region, no GPU work (CPU tests of --gpus N)")
+    ap.add_argument("--rows-extra-child", action="store_true", help=argparse.SUPPRESS)    # internal: see row_partition_extra
     return ap.parse_args()
 
 
@@ -296,68 +306,188 @@ def small_kernel_roofline(newton_passes, seconds, n_gpus):
                 note="latency-bound; HBM traffic is the problem data once, LDS bandwidth use is a few percent")
 
 
-ABANDON_COLLECTIVES = False      # set when the row-partition extra timed out: ranks may be stuck in a collective, so no further barrier
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _kill_group(p):
+    """ends exactly the process group this launcher created for child p (start_new_session=True), nothing else"""
+    try:
+        os.killpg(p.pid, signal.SIGKILL)
+    except (ProcessLookupError, PermissionError):
+        pass
 
 
 def row_partition_extra(a, rank, world, dist):
     """N > 1, default (independent-QP) mode: a short measurement of north_star's OTHER multi-GPU mode in the same run --
     ONE instance of the workload (seed 0) with the rows of A partitioned over the ranks and an all-reduce of A'y per
     product (RCCL on the solver's stream; QPDO_BENCH_ROWS_BACKEND=host: torch.distributed on host buffers, for ranks that
-    share a GPU) -- so that one driver SCALE run captures both modes.  Not part of `value`.  The first `passes` loop passes
-    of a cold solve (max_iter = passes), once to warm up and once timed, bracketed by barriers; max over ranks.
-    The RCCL exchange has never run on more than one rank before the first multi-GPU node sees this code (the build pool has one GPU
-    per box): the measurement runs on a watchdog thread, and if it has not finished within QPDO_BENCH_ROWS_TIMEOUT seconds (default
-    300) it is abandoned -- the main line is printed regardless and the process leaves without another collective."""
-    global ABANDON_COLLECTIVES
+    share a GPU) -- so that one driver SCALE run captures both modes.  Not part of `value`.
+    The RCCL exchange has never run on more than one rank before the first multi-GPU node sees this code (the build pool has one
+    GPU per box), so the measurement runs in a CHILD process per rank (`bench.py --rows-extra-child`, started after this rank has
+    released its workspaces; the children rendezvous among themselves on a port rank 0 picks): a child that has not finished
+    within QPDO_BENCH_ROWS_TIMEOUT seconds (default 90) is killed by its pid / process group and reported as an error, while this
+    process -- which never entered that collective -- prints the main line and leaves through its normal barrier with exit code 0."""
+    limit = float(os.environ.get("QPDO_BENCH_ROWS_TIMEOUT", "90"))
+    box = [_free_port() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(box[0]), RANK=str(rank), WORLD_SIZE=str(world),
+               LOCAL_RANK=os.environ.get("LOCAL_RANK", str(rank)))
+    cmd = [sys.executable, os.path.abspath(__file__), "--rows-extra-child", "--gpus", str(world), "--workload", a.workload]
+    t0 = time.time()
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True, cwd=ROOT)
+    try:
+        so, se = p.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        _kill_group(p)
+        so, se = p.communicate()
+        return dict(error="timed out after %.0f s: the child process of this rank was killed; the main measurement is unaffected" % limit,
+                    stderr_tail=(se or "")[-400:])
+    lines = [l for l in (so or "").splitlines() if l.startswith("{")]
+    if rank != 0:
+        return None
+    if p.returncode != 0 or not lines:
+        return dict(error="child exited with code %s" % p.returncode, stderr_tail=(se or "")[-600:])
+    res = json.loads(lines[-1])
+    res["wall_s_incl_process_start"] = time.time() - t0
+    return res
+
+
+def rows_extra_child(a):
+    """body of `--rows-extra-child` (one process per rank, see row_partition_extra): the first `passes` loop passes of a cold solve
+    of seed 0 (max_iter = passes), once to warm up and once timed, bracketed by barriers; max over ranks; rank 0 prints the JSON."""
+    rank, world, dist = dist_setup(a.gpus)
     from qpdo_amd import problems, solver
     passes = int(os.environ.get("QPDO_BENCH_ROWS_PASSES", "16"))
     mode = os.environ.get("QPDO_BENCH_ROWS_BACKEND", "rccl")
-    limit = float(os.environ.get("QPDO_BENCH_ROWS_TIMEOUT", "300"))
     res = dict(workload="%s seed 0, rows of A partitioned over %d ranks, the first %d loop passes of a cold solve (max_iter=%d)" % (a.workload, world, passes, passes),
                backend="RCCL all-reduce on the solver's stream" if mode == "rccl" else "torch.distributed (gloo) on host buffers")
+    prob = problems.config_qp(a.workload, index=0)
+    times = []
+    for rep in range(2):
+        if solver.dist_config(rank, world, mode=mode) != 0:          # an RCCL unique id is one-shot: a fresh one per workspace
+            raise RuntimeError("qpdo_amd_dist_config failed")
+        t0 = time.time()
+        s = solver.QPDO().setup(prob["Q"], prob["q"], prob["A"], prob["l"], prob["u"], Qstype=-1, verbose=0, max_iter=passes)
+        t_setup = time.time() - t0
+        barrier(dist)
+        t0 = time.time()
+        r = s.solve()
+        solver.lib().qpdo_amd_sync(s._w)
+        barrier(dist)
+        times.append(time.time() - t0)
+        stt = s.stats()
+        s.delete()
+    dt = allreduce(dist, [times[-1]], "max")[0]
+    res.update(seconds=dt, setup_s=t_setup, newton_passes=stt["newton_passes"], newton_iters_per_s=stt["newton_passes"] / dt,
+               iterations=r["info"]["iterations"], status_val=r["info"]["status_val"], cg_iters=stt["lin_iters"],
+               collectives=stt["collectives"], inner_collectives=stt["inner_collectives"], inner_steps=stt["inner_steps"],
+               inner_solves=stt["inner_solves"], schur_passes=stt["schur_passes"], scaling="strong")
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
-    def body():
-        try:
-            prob = problems.config_qp(a.workload, index=0)
-            times = []
-            for rep in range(2):
-                if solver.dist_config(rank, world, mode=mode) != 0:          # an RCCL unique id is one-shot: a fresh one per workspace
-                    raise RuntimeError("qpdo_amd_dist_config failed")
-                t0 = time.time()
-                s = solver.QPDO().setup(prob["Q"], prob["q"], prob["A"], prob["l"], prob["u"], Qstype=-1, verbose=0, max_iter=passes)
-                t_setup = time.time() - t0
-                barrier(dist)
-                t0 = time.time()
-                r = s.solve()
-                solver.lib().qpdo_amd_sync(s._w)
-                barrier(dist)
-                times.append(time.time() - t0)
-                stt = s.stats()
-                s.delete()
-            dt = allreduce(dist, [times[-1]], "max")[0]
-            res.update(seconds=dt, setup_s=t_setup, newton_passes=stt["newton_passes"], newton_iters_per_s=stt["newton_passes"] / dt,
-                       iterations=r["info"]["iterations"], status_val=r["info"]["status_val"], cg_iters=stt["lin_iters"],
-                       collectives=stt["collectives"], inner_collectives=stt["inner_collectives"], inner_steps=stt["inner_steps"],
-                       inner_solves=stt["inner_solves"], schur_passes=stt["schur_passes"], scaling="strong")
-        except Exception as e:
-            res["error"] = repr(e)
 
-    th = threading.Thread(target=body, daemon=True)
-    th.start()
-    th.join(limit)
-    if th.is_alive():
-        ABANDON_COLLECTIVES = True
-        return dict(res, error="timed out after %.0f s (abandoned; no further collective in this process)" % limit)
+# ---- --gpus N without a launcher: this process starts the N ranks itself ---------------------------------------------------
+def visible_gpu_count():
+    """GPUs this process may use.  The launcher must not create a HIP context (it only starts children), so it does not load
+    libqpdo_amd: HIP_/ROCR_VISIBLE_DEVICES when set, otherwise torch.cuda.device_count() (a count, no context on this image)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
     try:
-        solver.dist_config(0, 1)
+        import torch
+        return int(torch.cuda.device_count())
     except Exception:
-        pass
-    return res
+        return 0
+
+
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N ...` with no RANK / WORLD_SIZE in the environment: start N copies of this script, one per GPU
+    (RANK = LOCAL_RANK = r, rendezvous on 127.0.0.1 and a free port), relay rank 0's JSON line and return the worst exit code.
+    Each child is its own session, so a hung run is ended by killing exactly the process groups created here.  Fewer than N
+    visible GPUs is an error (QPDO_BENCH_SHARE_GPU=1: let the ranks share what there is -- tests on a one-GPU box)."""
+    n = a.gpus
+    if not a.launch_check and not os.environ.get("QPDO_BENCH_SHARE_GPU"):
+        have = visible_gpu_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d asked for, %d visible: refusing to report an N-GPU figure from fewer devices\n" % (n, have))
+            return 2
+    limit = float(os.environ.get("QPDO_BENCH_LAUNCH_TIMEOUT", "3000"))
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=os.getcwd(), start_new_session=True,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+
+    def _stop(signum, frame):
+        for p in procs:
+            _kill_group(p)
+        sys.exit(128 + signum)
+    signal.signal(signal.SIGTERM, _stop)
+    signal.signal(signal.SIGINT, _stop)
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    rd.start()
+    t0 = time.time()
+    worst, failed_at = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            worst = max((abs(c) for c in codes), default=0)
+            break
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad and failed_at is None:
+            failed_at = time.time()
+        if (failed_at is not None and time.time() - failed_at > 10.0) or time.time() - t0 > limit:
+            why = "a rank failed" if failed_at is not None else "no result after %.0f s" % limit
+            sys.stderr.write("bench.py: %s; ending the remaining ranks\n" % why)
+            for p in procs:
+                if p.poll() is None:
+                    _kill_group(p)
+            for p in procs:
+                p.wait()
+            worst = max([abs(c) for c in bad] + [1])
+            break
+        time.sleep(0.1)
+    rd.join(5.0)
+    for line in out0:
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    return worst
 
 
 def main():
     a = parse()
+    if a.rows_extra_child:
+        return rows_extra_child(a)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a, sys.argv[1:]))             # (nothing above this line loads the library or touches HIP)
     rank, world, dist = dist_setup(a.gpus)
+    if world != max(1, a.gpus):
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks: refusing to report an inconsistent n_gpus\n" % (a.gpus, world))
+        sys.exit(2)
+    if a.launch_check:
+        # the control plane of a timed region without GPU work: barrier, max over ranks of a per-rank time, sum over ranks of a count
+        barrier(dist)
+        t0 = time.time()
+        time.sleep(0.01 * (rank + 1))
+        barrier(dist)
+        dt_max = allreduce(dist, [time.time() - t0], "max")[0]
+        tot = allreduce(dist, [float(rank + 1)], "sum")[0]
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "sum_of_rank_plus_one": tot,
+                              "seconds_max_over_ranks": dt_max, "workload": a.workload}), flush=True)
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
     from qpdo_amd import problems, solver
     if a.workload == "C3":
         out = run_batch(a, rank, world, dist)
@@ -627,8 +757,6 @@ def main():
             out.setdefault("other_configs", {})["error"] = repr(e)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if ABANDON_COLLECTIVES:
-        os._exit(0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

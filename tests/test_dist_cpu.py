@@ -57,3 +57,40 @@ def test_two_rank_batch_shards_gloo():
     assert a["indices"] == [0, 2, 4, 6, 8, 10] and b["indices"] == [1, 3, 5, 7, 9]
     assert a["made"] == a["indices"] and b["made"] == b["indices"]
     assert a["seeds"][0] != b["seeds"][0]
+
+
+def _bare_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "QPDO_DEVICE")}
+    return env
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher environment must start two ranks itself (before anything touches HIP), relay rank
+    0's single JSON line and report n_gpus == 2 -- the shape of the driver's N = 1 command with N changed.  --launch-check keeps the
+    ranks off the GPU: rendezvous, barriers and the max / sum reductions of the timed region only."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C1", "--steps", "3", "--warmup", "1", "--launch-check"],
+                         env=_bare_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["sum_of_rank_plus_one"] == 3.0
+    assert r["seconds_max_over_ranks"] >= 0.02                # rank 1 slept longer: the max over ranks, not rank 0's own time
+
+
+def test_bench_gpus_n_refuses_fewer_devices_than_ranks():
+    """no GPU in this container: a real (not --launch-check) run with --gpus 2 must exit non-zero with a message instead of
+    reporting a one-GPU figure as n_gpus = 2 (or n_gpus = 1 for a command that asked for 2)"""
+    env = dict(_bare_env(), HIP_VISIBLE_DEVICES="0")          # one device visible at most
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C1", "--steps", "1"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0
+    assert "--gpus 2" in out.stderr and "visible" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_rank_count_must_match_gpus_flag():
+    """a launcher that started 2 ranks for `--gpus 1` (or the reverse) is an error, not a silently different n_gpus"""
+    env = dict(_bare_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "refusing" in out.stderr

@@ -147,14 +147,16 @@ print(json.dumps(dict(counts=[r["info"][k] == ro["info"][k] for k in ("status_va
 @pytest.mark.parametrize("workload,extra", [("C2", ["--steps", "3", "--warmup", "1", "--no-cpu-baseline"]),
                                             ("C3", ["--steps", "2", "--warmup", "1", "--max-iter", "300", "--batch-count", "512", "--no-cpu-baseline"])])
 def test_bench_contract_with_two_ranks_on_one_gpu(workload, extra, gpu_required):
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU; here both ranks land on the one GPU):
+    """bench.py for N > 1, as the BARE command `python bench.py --gpus 2 ...` with no launcher environment: the script starts its own two
+    ranks (here both land on the one GPU: QPDO_BENCH_SHARE_GPU=1; without it fewer than N visible devices is an error) and relays
     one JSON line from rank 0 with the whole-job aggregate; C2: independent QPs, each rank cycling through two seeded instances;
-    C3: the batch sharded over the ranks"""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29613" if workload == "C2" else "29614", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload] + extra
+    C3: the batch sharded over the ranks.  (The driver's torch.distributed.run form reaches the same code past the launcher.)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload] + extra
     # both ranks share the one GPU, where RCCL cannot form a 2-rank communicator: the row-partitioned extra of the default mode
     # exchanges through torch.distributed on host buffers here (a multi-GPU node uses RCCL)
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, QPDO_BENCH_ROWS_BACKEND="host", QPDO_BENCH_ROWS_PASSES="8"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "QPDO_DEVICE")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env=dict(env, QPDO_BENCH_ROWS_BACKEND="host", QPDO_BENCH_ROWS_PASSES="8", QPDO_BENCH_SHARE_GPU="1"))
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                  # rank 0 only
