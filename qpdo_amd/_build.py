@@ -60,12 +60,13 @@ def build_lib(force=False, verbose=False):
         raise RuntimeError("hipcc not found: libqpdo_amd.so cannot be built")
     objs = []
     common = ["-O3", "-fPIC", "-I", INCLUDE, "-I", CSRC]
-    for s in HIP_SOURCES:
-        o = os.path.join(CSRC, s + ".o")
+
+    def hip_object(src):
+        o = os.path.join(CSRC, src + ".o")
         # -amdgpu-mfma-vgpr-form: accumulators of the fp64 MFMA loops stay in VGPRs; the default heuristics put them in AGPRs inside
         # the loop and in VGPRs across its back edge (64 v_accvgpr moves and a drained matrix pipeline per 16 MFMAs in k_ldl_syrk)
         cmd = [cc, "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
-               "-mllvm", "-amdgpu-mfma-vgpr-form", *common, "-c", os.path.join(CSRC, s), "-o", o]
+               "-mllvm", "-amdgpu-mfma-vgpr-form", *common, "-c", os.path.join(CSRC, src), "-o", o]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         try:
@@ -75,7 +76,10 @@ def build_lib(force=False, verbose=False):
             i = cmd.index("-amdgpu-mfma-vgpr-form")
             del cmd[i - 1:i + 1]
             subprocess.check_call(cmd)
-        objs.append(o)
+        return o
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(HIP_SOURCES)) as ex:          # the translation units side by side
+        objs.extend(ex.map(hip_object, HIP_SOURCES))
     for s in C_SOURCES:
         o = os.path.join(CSRC, s + ".o")
         subprocess.check_call(["gcc", "-std=gnu11", "-ffp-contract=off", "-fopenmp", "-Wall", *common,
@@ -86,6 +90,25 @@ def build_lib(force=False, verbose=False):
     subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-lm", "-lpthread",
                            "-L/opt/rocm/lib", "-lrccl", gomp])
     return LIB_PATH
+
+
+def build_lib_testhooks(out_dir):
+    """A TEST build of the product library with -DQPDO_TEST_HOOKS (fault injection into the chained triangular solves:
+    QPDO_DENSE_CHAIN_INJECT).  The hooks are compiled out of libqpdo_amd.so; this variant goes to out_dir and is loaded through
+    QPDO_AMD_LIB by the one test that needs it.  Only qpdo_dev.hip is recompiled; the other objects are the product's."""
+    cc = hipcc()
+    if cc is None:
+        raise RuntimeError("hipcc not found")
+    build_lib()
+    os.makedirs(out_dir, exist_ok=True)
+    o = os.path.join(out_dir, "qpdo_dev_testhooks.o")
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-DQPDO_TEST_HOOKS",
+                           "-O3", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c", os.path.join(CSRC, "qpdo_dev.hip"), "-o", o])
+    so = os.path.join(out_dir, "libqpdo_amd_testhooks.so")
+    gomp = subprocess.check_output(["gcc", "-print-file-name=libgomp.so"], text=True).strip()
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, o, os.path.join(CSRC, "qpdo_small.hip.o"),
+                           os.path.join(CSRC, "qpdo_api.c.o"), "-lm", "-lpthread", "-L/opt/rocm/lib", "-lrccl", gomp])
+    return so
 
 
 def ensure_lib():

@@ -130,8 +130,17 @@ static QPDOSettings *copy_settings(const QPDOSettings *s) {   /* src/util.c:21-4
 /* The batch stream (qpdo_amd_batch_stream_*) keeps up to `depth` fused-kernel launches in flight on separate HIP streams.  The
  * runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that share a queue serialise: measured
  * on MI355X, 16 batches of 4096 C3 QPs at depth 12: 7.0 k QP/s on 4 queues, 10.1 k on 16.  The variable is read when the HIP
- * runtime initialises (the first HIP call of the process), so it is set -- never overridden -- when this library is loaded. */
-__attribute__((constructor)) static void qpdo_amd_on_load(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+ * runtime initialises (the first HIP call of the process).  This library does NOT touch its host's environment: the caller sets
+ * GPU_MAX_HW_QUEUES before its first HIP call (the Python front end does so before it loads the library), and
+ * qpdo_amd_batch_stream_create says so once when a deep stream is created without it. */
+static void warn_hw_queues_once(int depth) {
+    static int warned = 0;
+    const char *v = getenv("GPU_MAX_HW_QUEUES");
+    const int have = (v && *v) ? atoi(v) : 4;
+    if (depth > have && !__sync_lock_test_and_set(&warned, 1))
+        fprintf(stderr, "qpdo_amd: batch stream of depth %d on %d HIP hardware queues (GPU_MAX_HW_QUEUES%s): streams that share a queue "
+                        "serialise; export GPU_MAX_HW_QUEUES=%d before the process's first HIP call\n", depth, have, (v && *v) ? "" : " unset", depth > 16 ? depth : 16);
+}
 
 static int env_int_early(const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
 static double wall_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
@@ -914,6 +923,7 @@ QPDOAmdBatchStream *qpdo_amd_batch_stream_create(int depth) {
     int ndev = qdev_device_count();
     if (ndev <= 0) { QPDO_EPRINT("no HIP device available (this library has no CPU path)"); return NULL; }
     int device = env_int("QPDO_DEVICE", env_int("LOCAL_RANK", 0)) % ndev;
+    warn_hw_queues_once(depth);
     return (QPDOAmdBatchStream *)qdev_small_stream_create(device, depth);
 }
 long qpdo_amd_batch_stream_submit(QPDOAmdBatchStream *stream, long count, QPDOAmdBatchItem *items, const QPDOSettings *settings) {

@@ -1182,7 +1182,8 @@ static int pinned_reserve(char **buf, size_t *cap, size_t need) {
     *cap = want;
     return 0;
 }
-static double s_last_kernel_s = 0.0;          // HIP-event duration of the last finished k_small_solve launch (bench.py's latency statement)
+static volatile double s_last_kernel_s = 0.0;   // (a statistic: written by whichever batch finished last; an aligned 8-byte store)
+//          // HIP-event duration of the last finished k_small_solve launch (bench.py's latency statement)
 
 // pack the batch into the slot's staging buffer, upload, launch, enqueue the downloads: returns without waiting for the GPU
 static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *items, const QPDOSettings *settings) {
@@ -1301,6 +1302,9 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
     S.count = count; S.items = items; S.upload_bytes = upload_bytes; S.out_bytes = out_bytes; S.busy = true;
     lap("enqueue");
 done:
+    // a failure after work was enqueued (the upload, the launch): the pinned staging and the arena must not be repacked, regrown or
+    // freed by the next submit while that work is still in flight
+    if (rc && S.stream) (void)hipStreamSynchronize(S.stream);
     return rc;
 }
 // wait for the slot's batch and hand the results to its items
@@ -1335,8 +1339,8 @@ static int slot_finish(SmallSlot &S) {
         if (items[i].y) for (size_t k = 0; k < m; k++) items[i].y[k] = infeasible ? NAN : sy[k];
     });
 done:
-    S.busy = false;
-    return rc;
+    if (rc && S.stream) (void)hipStreamSynchronize(S.stream);
+    return rc;                                     // (S.busy is cleared by the caller, under the lock that guards the slots)
 }
 
 struct SmallStream { int device; std::vector<SmallSlot> slots; long next_ticket = 0; std::mutex mu; };
@@ -1376,7 +1380,7 @@ int qdev_small_batch(int device, long count, void *items_, const void *settings_
     std::lock_guard<std::mutex> lock(s_slot0_mu);
     int rc = slot_submit(s_slot0, device, count, (QPDOAmdBatchItem *)items_, (const QPDOSettings *)settings_);
     if (rc == 0) rc = slot_finish(s_slot0);
-    else s_slot0.busy = false;
+    s_slot0.busy = false;
     return rc;
 }
 
@@ -1409,14 +1413,15 @@ int qdev_small_stream_wait(void *h, long ticket, double *kernel_seconds) {
     SmallSlot *S = nullptr;
     { std::lock_guard<std::mutex> lock(T->mu); for (SmallSlot &c : T->slots) if (c.busy && c.ticket == ticket) S = &c; }
     if (!S) { snprintf(s_err, sizeof(s_err), "batch stream: ticket %ld is not in flight", ticket); return -1; }
-    const int rc = slot_finish(*S);
+    const int rc = slot_finish(*S);                // (outside the lock: other tickets may be submitted / waited for meanwhile)
     if (kernel_seconds) *kernel_seconds = S->kernel_s;
+    { std::lock_guard<std::mutex> lock(T->mu); S->busy = false; }
     return rc;
 }
 void qdev_small_stream_destroy(void *h) {
     SmallStream *T = (SmallStream *)h;
     if (!T) return;
-    for (SmallSlot &S : T->slots) { if (S.busy) (void)slot_finish(S); slot_release(S); }
+    for (SmallSlot &S : T->slots) { if (S.busy) { (void)slot_finish(S); S.busy = false; } slot_release(S); }
     delete T;
 }
 

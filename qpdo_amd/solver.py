@@ -9,6 +9,7 @@ Every numerical call goes through the C entry points declared in include/qpdo.h;
 Python or CPU implementation behind this class.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import scipy.sparse as sp
@@ -113,6 +114,11 @@ def lib():
     """Loads libqpdo_amd.so (building it in-tree if needed).  Raises if it is unavailable."""
     global _lib
     if _lib is None:
+        # batch streams keep up to `depth` launches in flight on separate HIP streams; two streams that share one of the runtime's
+        # GPU_MAX_HW_QUEUES (default 4) hardware queues serialise (7.0 k vs 10.1 k QP/s at depth 12).  The variable is read at the
+        # process's first HIP call, so it is the CALLER's to set: this front end does it here, before the library is loaded -- the
+        # library itself never changes its host's environment (INTEGRATION.md).  No effect if HIP was initialised earlier.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         L = C.CDLL(_build.ensure_lib())
         W = C.POINTER(QPDOWorkspace)
         L.qpdo_set_default_settings.argtypes = [C.POINTER(QPDOSettings)]

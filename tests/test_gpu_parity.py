@@ -665,17 +665,39 @@ def test_pcg_that_cannot_converge_is_an_error_not_a_silent_step(gpu_required, mo
     # relative residual far above 1e-12 when the right-hand side of a late pass is itself of the order of 1e-6)
 
 
-def test_lost_producer_of_a_chained_solve_is_redone_stepwise_not_an_error(gpu_required, monkeypatch):
+def test_lost_producer_of_a_chained_solve_is_redone_stepwise_not_an_error(gpu_required, tmp_path):
     """round-1 advisor finding: a chained triangular solve that loses a producer ended the whole qpdo_solve with QPDO_ERROR.  Now the
     iterate update of that pass is skipped on the device and the step is redone with the stepwise solves on a fresh factor; injected
-    at Newton pass 3, the solve must still reproduce the oracle -- counts, trace, iterates"""
-    monkeypatch.setenv("QPDO_LINSOLVE", "dense")
-    monkeypatch.setenv("QPDO_DENSE_CHAIN_INJECT", "3")
+    at Newton pass 3, the solve must still reproduce the oracle -- counts, trace, iterates.  The injection hook is compiled only into a
+    TEST build of the library (-DQPDO_TEST_HOOKS, _build.build_lib_testhooks), loaded by a child process through QPDO_AMD_LIB: the
+    product library does not contain it."""
+    import json, subprocess, sys
+    from qpdo_amd import _build
+    so = _build.build_lib_testhooks(str(tmp_path))
+    code = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+from qpdo_amd import problems, solver
+p = problems.random_qp(43, 1000, 700, 0.03, 50)
+r = solver.solve_problem(p, verbose=0)
+print(json.dumps(dict(info=r["info"], x=r["x"].tolist(), y=r["y"].tolist(), stats=r["stats"], trace=r["trace"])))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, QPDO_LINSOLVE="dense", QPDO_DENSE_CHAIN_INJECT="3")
+    outs = {}
+    for label, libpath in (("hooks", so), ("product", None)):
+        e = dict(env)
+        if libpath:
+            e["QPDO_AMD_LIB"] = libpath
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
+        assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+        outs[label] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert outs["hooks"]["stats"]["chain_fallbacks"] == 1
+    assert outs["product"]["stats"]["chain_fallbacks"] == 0           # the product library ignores the variable: no hook in it
     p = problems.random_qp(43, 1000, 700, 0.03, 50)
-    r = solver.solve_problem(p, verbose=0)
-    assert r["stats"]["chain_fallbacks"] == 1
     o = ob.OracleSolver(p, ob.default_settings())
     ro = o.solve()
-    assert_same_outcome(r, ro["info"], ro["x"], ro["y"], p)
-    assert_same_trace(r["trace"], o.trace())
+    for r in outs.values():
+        r = dict(r, x=np.array(r["x"]), y=np.array(r["y"]))
+        assert_same_outcome(r, ro["info"], ro["x"], ro["y"], p)
+        assert_same_trace(r["trace"], o.trace())
     o.close()
