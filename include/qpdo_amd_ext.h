@@ -28,6 +28,8 @@
  *   QPDO_PCG_ABS     factor f of the absolute stopping rule of the PCG solve: stop when the residual, in the unscaled inf-norm of
  *                    the reference's inner dual residual, is <= f * eps_abs (default 1e-5; 0: relative rule only; proximal only)
  *   QPDO_PCG_MAXIT   PCG iteration cap per Newton step (default 100000)
+ *   QPDO_SMALL_FUSED "0": never route qpdo_solve through the fused one-launch kernel (default: workspaces with n <= QPDO_SMALL_FUSED_MAX_N
+ *                    = 160, m <= 1024 whose packed Newton matrix fits one workgroup's LDS, verbose = 0, no explicit QPDO_LINSOLVE)
  *   QPDO_FIX_STATUS_RESET  "1": reset info->status_val at the start of qpdo_solve
  *                    (the reference does not: src/qpdo.c:451-453 vs :200)
  */
@@ -57,7 +59,7 @@ typedef struct {
     long   spmv_calls;      /* SpMV launches in the last solve                             */
     double spmv_alg_bytes;  /* sum over those launches of 12 nnz + 4(rows+1) + 8 rows + 8 cols */
     long   factor_count;    /* dense LDL' factorizations                                   */
-    long   linsolve;        /* 0 pcg, 1 dense                                              */
+    long   linsolve;        /* 0 pcg, 1 dense, 2 fused small-problem kernel                */
     double spmv_Q_avg_s;    /* HIP-event average duration of the sampled Q SpMV inside PCG */
     long   spmv_Q_samples;
     double spmv_Ac_time_s;  /* Schur-mode inner solves: summed HIP-event time of the sampled A_c products ...          */
@@ -77,6 +79,9 @@ typedef struct {
     double pcg_max_relres;  /* largest ||r||/||rhs|| a PCG solve of the last qpdo_solve ended with (tolerance QPDO_PCG_TOL)      */
     long   pcg_dense_fallbacks; /* PCG solves that could not converge (relative residual > 1e-8: e.g. settings->proximal = 0 on a singular
                              * Q + A'DA) and were redone by the dense LDL' solver, which the rest of that qpdo_solve then keeps (n <= 18000) */
+    long   fused_solves;    /* qpdo_solve calls of this workspace that ran as ONE launch of the fused small-problem kernel (then linsolve = 2:
+                             * in-LDS natural-order LDL' in the oracle's operation order, factor_count = its factorizations)                  */
+    double fused_kernel_s;  /* HIP-event duration of that launch in the last qpdo_solve (0 if it took the generic path)                     */
 } QPDOAmdStats;
 
 int  qpdo_amd_device_count(void);

@@ -30,6 +30,13 @@ struct QPDOBackend {
     int fix_status_reset;
     QPDOAmdTraceRec *trace; long ntrace, captrace;
     long newton_passes;
+    /* small problems (the packed Newton matrix fits one workgroup's LDS, n <= QPDO_SMALL_FUSED_MAX_N): qpdo_solve runs as ONE launch of
+     * the fused kernel on the workspace's own device arrays (qdev_small_resident_*), in the oracle's operation order */
+    void *small;                  /* resident fused-solve handle, or NULL: generic multi-kernel path */
+    int ws_state;                 /* the workspace's device vectors hold the warm-started state of the pending solve (0: qpdo_solve's automatic
+                                   * cold start of a fused-path workspace, which is part of the solve's launch) */
+    int auto_ws;                  /* qpdo_warm_start is being called by qpdo_solve itself (qpdo.c:312-314) */
+    long fused_solves, fused_factor_count; double fused_kernel_s; int last_fused;
 };
 
 #define c_max(a, b) (((a) > (b)) ? (a) : (b))
@@ -511,6 +518,18 @@ QPDOWorkspace *qpdo_setup(const QPDOData *data, const QPDOSettings *settings) {
         if (qdev_set_scaling(work->chol->dev, 0, NULL, NULL, NULL, NULL, 1.0, 1.0)) goto fail_dev;
         work->norm_q = vec_norm_inf(work->data->q, n);
     }
+    {   /* small problems: the fused one-launch solve (QPDO_SMALL_FUSED=0 keeps the generic path; an explicit QPDO_LINSOLVE asks for one
+         * of the generic path's solvers; a row-partitioned workspace is never small) */
+        const char *ls = getenv("QPDO_LINSOLVE");
+        const int want = env_int("QPDO_SMALL_FUSED", 1) && !(ls && *ls && strcmp(ls, "auto"));
+        if (want && (long)n <= env_int("QPDO_SMALL_FUSED_MAX_N", 160) && qdev_small_resident_fits((int32_t)n, (int32_t)m)) {
+            QdevSmallView v;
+            if (qdev_small_view(work->chol->dev, &v) == 0) {
+                long cap = (long)settings->max_iter < 16384 ? (long)settings->max_iter : 16384;
+                work->chol->small = qdev_small_resident_create(&v, cap);      /* NULL: not fatal, the generic path serves the workspace */
+            }
+        }
+    }
     update_status(work->info, QPDO_UNSOLVED);
     work->info->solve_time = 0.0;
     work->info->run_time = 0.0;
@@ -530,9 +549,36 @@ void qpdo_warm_start(QPDOWorkspace *work, c_float *x_warm_start, c_float *y_warm
     if (work->info->status_val != QPDO_UNSOLVED) work->info->setup_time = 0;
     tic(work->timer);
     c_float obj = 0.0;
+    if (work->chol->small && work->chol->auto_ws && !work->settings->verbose) {
+        /* qpdo_solve's automatic warm start (qpdo.c:312-314, x = y = 0) of a fused-path workspace: nothing can come between it and the
+         * solve, so it is part of the solve's one launch -- nothing to do on the device here */
+        work->chol->ws_state = 0;
+        work->info->objective = 0.0;
+        work->sqrt_mu_min = 1 / sqrt(work->settings->mu_min);
+        work->initialized = 1;
+        work->info->setup_time += toc(work->timer);
+        return;
+    }
+    if (work->chol->small) {
+        /* an explicit warm start of a fused-path workspace: x, x_bar, Qx, Ax, y, y_bar, A'y, mu in the ORACLE's operation order (one
+         * workgroup, qpdo_small.hip mode 1) into the workspace's device vectors; qpdo_update_q / _bounds may then act on them as in the
+         * reference before the solve reads them back (mode 2) */
+        QdevSmallView v;
+        if (qdev_small_view(work->chol->dev, &v) ||
+            qdev_small_resident_warm_start(work->chol->small, &v, work->settings, x_warm_start, y_warm_start, work->data->c, &obj)) {
+            QPDO_EPRINT("fused small-problem warm start: %s / %s", qdev_small_last_error(), qdev_last_error()); update_status(work->info, QPDO_ERROR); return;
+        }
+        work->chol->ws_state = 1;
+        work->info->objective = x_warm_start ? obj : 0.0;
+        work->sqrt_mu_min = 1 / sqrt(work->settings->mu_min);
+        work->initialized = 1;
+        work->info->setup_time += toc(work->timer);
+        return;
+    }
     int rc = qdev_warm_start(work->chol->dev, x_warm_start, y_warm_start, (int)work->settings->proximal, work->sigma,
                              work->settings->mu_min, work->data->c, &obj);
     if (rc) { QPDO_EPRINT("device backend: %s", qdev_last_error()); update_status(work->info, QPDO_ERROR); return; }
+    work->chol->ws_state = 1;
     work->info->objective = x_warm_start ? obj : 0.0;
     work->sqrt_mu_min = 1 / sqrt(work->settings->mu_min);      /* iteration.c:121 */
     work->initialized = 1;
@@ -572,6 +618,53 @@ static void print_final_message(QPDOWorkspace *work) {   /* src/util.c:122-173 *
     QPDO_PRINT("============================================================================\n\n");
 }
 
+/* ---- qpdo_solve of a small workspace: ONE launch of the fused kernel (qpdo_small.hip) on the workspace's device arrays --------------
+ * Same loop (src/qpdo.c:343-449) in the oracle's operation order, so status, counts and iterates carry the oracle's bits.  Called by
+ * qpdo_solve after its prologue (header, automatic warm start, eps_in / sigma / reset_newton, status quirk Q1, tic, trace reset). */
+static void fused_solve(QPDOWorkspace *work) {
+    struct QPDOBackend *be = work->chol;
+    QPDOSettings st = *work->settings;
+    QdevSmallView v;
+    QdevSmallResult res;
+    QPDOInfo kinfo;
+    memset(&res, 0, sizeof(res)); memset(&kinfo, 0, sizeof(kinfo));
+    res.info = &kinfo;
+    /* max_time (qpdo.c:441-447) counts from the start of setup: run_time = setup_time + time in the solve; the kernel's clock starts now */
+    if (st.max_time < 1e19) st.max_time -= work->info->setup_time;
+    const c_int status_before = work->info->status_val;
+    if (qdev_small_view(be->dev, &v) ||
+        qdev_small_resident_solve(be->small, &v, &st, be->ws_state, work->data->c, &res)) {
+        QPDO_EPRINT("fused small-problem solve: %s / %s", qdev_small_last_error(), qdev_last_error());
+        update_status(work->info, QPDO_ERROR);
+        work->initialized = 0;
+        work->info->solve_time = toc(work->timer);
+        work->info->run_time = work->info->setup_time + work->info->solve_time;
+        return;
+    }
+    const size_t n = work->data->n, m = work->data->m;
+    work->info->iterations = kinfo.iterations; work->info->oterations = kinfo.oterations;
+    work->info->res_prim_norm = kinfo.res_prim_norm; work->info->res_dual_norm = kinfo.res_dual_norm;
+    work->info->res_prim_in_norm = kinfo.res_prim_in_norm; work->info->res_dual_in_norm = kinfo.res_dual_in_norm;
+    work->info->objective = kinfo.objective;
+    /* quirk Q1 (qpdo.c:451-453): only an UNSOLVED status is overwritten when the loop runs out of passes */
+    if (kinfo.status_val == QPDO_MAX_ITER_REACHED) { if (status_before == QPDO_UNSOLVED || be->fix_status_reset) update_status(work->info, QPDO_MAX_ITER_REACHED); }
+    else update_status(work->info, kinfo.status_val);
+    work->sigma = res.sigma_end; work->tau = res.tau_end;
+    memcpy(work->solution->x, res.sol_x, n * sizeof(c_float)); memcpy(work->x, res.x, n * sizeof(c_float)); memcpy(work->dx, res.dx, n * sizeof(c_float));
+    if (m) { memcpy(work->solution->y, res.sol_y, m * sizeof(c_float)); memcpy(work->y, res.y, m * sizeof(c_float)); memcpy(work->dy, res.dy, m * sizeof(c_float)); }
+    be->newton_passes = res.newton_passes; be->last_fused = 1; be->fused_solves++; be->fused_factor_count = res.factor_count; be->fused_kernel_s = res.kernel_seconds;
+    /* the per-pass trace (pinned records written by the kernel) into the workspace's trace array */
+    if (res.ntrace > be->captrace) {
+        QPDOAmdTraceRec *t = realloc(be->trace, (size_t)res.ntrace * sizeof(*t));
+        if (t) { be->trace = t; be->captrace = res.ntrace; }
+    }
+    be->ntrace = res.ntrace <= be->captrace ? res.ntrace : be->captrace;
+    if (be->ntrace > 0) memcpy(be->trace, res.trace, (size_t)be->ntrace * sizeof(QPDOAmdTraceRec));
+    work->initialized = 0;
+    work->info->solve_time = toc(work->timer);
+    work->info->run_time = work->info->setup_time + work->info->solve_time;
+}
+
 #define DEVCALL(call) do { if ((call)) { QPDO_EPRINT("device backend: %s", qdev_last_error()); update_status(work->info, QPDO_ERROR); goto done; } } while (0)
 
 /* ---- qpdo_solve (reference src/qpdo.c:304-476) ---------------------------------------------- */
@@ -580,7 +673,7 @@ void qpdo_solve(QPDOWorkspace *work) {
     QpdoDev *dev = be->dev;
     const QPDOSettings *s;
     if (work->settings->verbose) print_header();
-    if (!work->initialized) qpdo_warm_start(work, NULL, NULL);
+    if (!work->initialized) { be->auto_ws = 1; qpdo_warm_start(work, NULL, NULL); be->auto_ws = 0; }
     s = work->settings;
     const int prox = (int)s->proximal;
     work->eps_in = s->eps_abs_in;
@@ -588,11 +681,17 @@ void qpdo_solve(QPDOWorkspace *work) {
     be->reset_newton = 1;
     if (be->fix_status_reset) update_status(work->info, QPDO_UNSOLVED);
     tic(work->timer);
-    be->ntrace = 0; be->newton_passes = 0;
+    be->ntrace = 0; be->newton_passes = 0; be->last_fused = 0;
     qdev_reset_stats(dev);
     c_int iter = 0, oter = 0, iter_old = 0;
     long tr_pending = -1;           /* index of the trace record whose tau is still in flight (deferred step read-back) */
     if (!work->initialized) goto done;      /* warm start failed on the device */
+    if (be->small && !s->verbose) { fused_solve(work); return; }
+    if (!be->ws_state) {                    /* (cannot happen: the automatic cold start is skipped only when this solve takes the fused path) */
+        c_float obj0 = 0.0;
+        DEVCALL(qdev_warm_start(dev, NULL, NULL, prox, work->sigma, s->mu_min, work->data->c, &obj0));
+        be->ws_state = 1;
+    }
     DEVCALL(qdev_begin_solve(dev));
     DEVCALL(qdev_set_eps_abs(dev, s->eps_abs));
     /* One host synchronisation per loop pass instead of two (dense solver; QPDO_DEFER_STEP=0 switches it off): the Newton step is
@@ -804,7 +903,7 @@ void qpdo_cleanup(QPDOWorkspace *work) {
     if (work->scaling) { free(work->scaling->D); free(work->scaling->Dinv); free(work->scaling->E); free(work->scaling->Einv); free(work->scaling); }
     free(work->x); free(work->y); free(work->dx); free(work->dy);
     free(work->settings);
-    if (work->chol) { qdev_destroy(work->chol->dev); free(work->chol->trace); free(work->chol); }
+    if (work->chol) { qdev_small_resident_destroy(work->chol->small); qdev_destroy(work->chol->dev); free(work->chol->trace); free(work->chol); }
     if (work->solution) { free(work->solution->x); free(work->solution->y); free(work->solution); }
     free(work->timer);
     free(work->info);
@@ -854,6 +953,9 @@ int qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out) {
     out->inner_steps = (long)st.inner_steps; out->inner_collectives = (long)st.inner_collectives;
     out->pcg_max_relres = st.pcg_max_relres;
     out->pcg_dense_fallbacks = (long)st.pcg_dense_fallbacks;
+    out->fused_solves = work->chol->fused_solves;
+    out->fused_kernel_s = work->chol->last_fused ? work->chol->fused_kernel_s : 0.0;
+    if (work->chol->last_fused) { out->factor_count = work->chol->fused_factor_count; out->linsolve = 2; }
     return 0;
 }
 

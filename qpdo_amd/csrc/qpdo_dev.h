@@ -174,6 +174,39 @@ long  qdev_small_stream_submit(void *stream, long count, void *items, const void
 int   qdev_small_stream_wait(void *stream, long ticket, double *kernel_seconds);
 void  qdev_small_stream_destroy(void *stream);
 
+/* ---- ONE small workspace through the fused kernel (the default path of qpdo_solve for problems whose whole state fits one
+ * workgroup's LDS): the kernel runs on the workspace's own device arrays -- matrices, q, l, u as qpdo_setup scaled them, the warm start
+ * as qpdo_warm_start left it -- and keeps the oracle's operation order, so its results are bit-identical to the oracle's. */
+typedef struct {
+    int device; void *stream;                            /* the workspace's HIP stream (hipStream_t)                        */
+    int32_t n, m;
+    const int32_t *Arp, *Aci; const double *Aval;        /* CSR(A)  m x n, rows column-sorted, scaled                       */
+    const int32_t *Trp, *Tci; const double *Tval;        /* CSR(A') n x m                                                   */
+    const int32_t *Qrp, *Qci; const double *Qval;        /* full symmetric CSR(Q), scaled (incl. the cost scaling c)        */
+    const double *q, *l, *u;                             /* scaled                                                          */
+    int scaled; const double *D, *Dinv, *E, *Einv; double c, cinv;
+    /* the workspace's iterate state: written by an explicit qpdo_warm_start (mode 1), adjusted by qpdo_update_q, read by the solve that
+     * follows (mode 2); every solve writes its final x and Qx back (qpdo_update_q reads them, qpdo.c:556-560) */
+    double *st_x, *st_xbar, *st_Qx, *st_Aty, *st_y, *st_ybar, *st_Ax, *st_mu, *st_isq;
+} QdevSmallView;
+typedef struct {
+    void *info;                                          /* QPDOInfo *: iterations, oterations, norms, objective, status    */
+    long newton_passes, factor_count, ntrace;
+    const void *trace;                                   /* QPDOAmdTraceRec[ntrace], valid until the next solve             */
+    const double *sol_x, *sol_y, *x, *y, *dx, *dy;       /* pinned host arrays owned by the handle, valid until the next solve */
+    double sigma_end, tau_end, kernel_seconds;
+} QdevSmallResult;
+int   qdev_small_view(QpdoDev *d, QdevSmallView *out);
+int   qdev_small_resident_fits(int32_t n, int32_t m);
+void *qdev_small_resident_create(const QdevSmallView *v, long trace_cap);
+/* an explicit qpdo_warm_start (qpdo.c:217-299) in the oracle's operation order: x_ws / y_ws are the caller's (unscaled) vectors or NULL */
+int   qdev_small_resident_warm_start(void *handle, const QdevSmallView *v, const void *settings /* QPDOSettings */, const double *x_ws,
+                                     const double *y_ws, double c_const, double *objective);
+/* from_state = 0: cold start (qpdo_solve's automatic warm start with NULLs) and solve in one launch; 1: solve from the workspace's state */
+int   qdev_small_resident_solve(void *handle, const QdevSmallView *v, const void *settings /* QPDOSettings */, int from_state,
+                                double c_const, QdevSmallResult *out);
+void  qdev_small_resident_destroy(void *handle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,26 @@ struct SmallQP {
     QPDOInfo info;
     long newton_passes, factor_count;
     long long *prof;                         // optional: per-phase wall-clock ticks (diagnostic runs only)
+    struct SmallRes *res;                    // resident mode (latency kernel only): see SmallRes; NULL in a batch
+};
+// ---- resident mode (qpdo_solve of ONE small workspace through the latency kernel, qdev_small_resident_*): the matrices, q, l, u are the
+// workspace's own device arrays, already scaled by qpdo_setup (bit-identical to the oracle's scaling), so the kernel skips its Ruiz
+// phase and takes D, E, c from the workspace; x0 / y0 are the workspace's warm-started x, y (already scaled by qpdo_warm_start).
+struct SmallRes {
+    const double *rD, *rDinv, *rE, *rEinv; double r_c, r_cinv;
+    // mode 0: the whole of warm start (from zero, or from x0 / y0) + solve in one launch -- qpdo_solve with its AUTOMATIC warm start
+    //         (qpdo.c:312-314), where nothing can come between the two.
+    // mode 1: an explicit qpdo_warm_start alone: x, x_bar, Qx, Ax, y, y_bar, A'y, mu, 1/sqrt(mu) in the oracle's operation order into the
+    //         workspace's vectors (st_*), the objective of qpdo.c:257 into ws_objective; the caller may then qpdo_update_q / _bounds --
+    //         those act on the workspace's vectors exactly as in the reference (qpdo.c:522-586) -- before
+    // mode 2: the solve loop from the workspace's state (st_* are read instead of a warm start).
+    int mode;
+    double *state_x, *state_Qx;              // modes 0, 2 out: final x and Qx into the workspace's vectors (qpdo_update_q reads them, qpdo.c:549-586); = st_x, st_Qx
+    double *st_xbar, *st_Ax, *st_y, *st_ybar, *st_Aty, *st_mu, *st_isq;
+    double ws_objective;
+    double *out_x, *out_y;                   // out: the internal (scaled) iterates, the host mirrors work->x / work->y (y after termination.c:85)
+    QPDOAmdTraceRec *trace; long trace_cap, ntrace;      // optional per-pass trace (pinned host memory), records written / capacity
+    double sigma_end, tau_end;
 };
 enum { NV_X = 0, NV_XBAR, NV_QX, NV_ATY, NV_DF, NV_RD, NV_RDI, NV_RHS, NV_DX, NV_QDX, NV_ATDY, NV_D, NV_DINV, NV_T, NV_COUNT };
 enum { MV_Y = 0, MV_YBAR, MV_AX, MV_MU, MV_ISQ, MV_W, MV_RP, MV_RPOLD, MV_RPI, MV_DY, MV_ADX, MV_DW, MV_E, MV_EINV, MV_ATS, MV_T, MV_DWF, MV_COUNT };
@@ -556,7 +576,7 @@ __device__ __forceinline__ void small_sort_regs(int np2, int M2, const double *l
 }
 // (its own function, not inlined: the kernel is held to 128 VGPRs, and inlined the register pressure of the sort and of the unrolled
 // folds below pushed spills into the factorization and solve loops -- measured: triangular solves 2x slower)
-__device__ __attribute__((noinline)) double small_linesearch(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, unsigned char *jflag, double *tm, double *sm, u64 *skey, u32 *sidx, double *gbuf) {
+__device__ __forceinline__ double small_linesearch_impl(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, unsigned char *jflag, double *tm, double *sm, u64 *skey, u32 *sidx, double *gbuf) {
     const int n = P.n, m = P.m;
     long long tls = P.prof ? wall_clock64() : 0;
 #define PHL(k) do { if (P.prof && threadIdx.x == 0) { const long long t_ = wall_clock64(); P.prof[k] += t_ - tls; tls = t_; } } while (0)
@@ -686,6 +706,10 @@ __device__ __attribute__((noinline)) double small_linesearch(SmallQP &P, double 
     SYNC;
     return sm[17];
 }
+// The batch kernel calls it out of line (see above); the latency variant, with twice the registers, inlines it (no pointer tables in scratch).
+__device__ __attribute__((noinline)) double small_linesearch(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, unsigned char *jflag, double *tm, double *sm, u64 *skey, u32 *sidx, double *gbuf) {
+    return small_linesearch_impl(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf);
+}
 
 __device__ void small_status(QPDOInfo &info, long st) {
     info.status_val = st;
@@ -705,6 +729,22 @@ __device__ void small_status(QPDOInfo &info, long st) {
     info.status[i] = 0;
 }
 
+// compute_objective (iteration.c:185-221), one lane: sum of (0.5 (Qx - sigma x) + q) x in the 4-way grouped order of the reference
+__device__ __forceinline__ double small_objective(int n, int prox, double sigma, const double *Qx, const double *x, const double *q) {
+    double obj = 0; int i = 0;
+    if (prox) {
+        if (n >= 4) for (; i <= n - 4; i += 4)
+            obj += (0.5 * (Qx[i] - x[i] * sigma) + q[i]) * x[i] + (0.5 * (Qx[i + 1] - x[i + 1] * sigma) + q[i + 1]) * x[i + 1] +
+                   (0.5 * (Qx[i + 2] - x[i + 2] * sigma) + q[i + 2]) * x[i + 2] + (0.5 * (Qx[i + 3] - x[i + 3] * sigma) + q[i + 3]) * x[i + 3];
+        for (; i < n; i++) obj += (0.5 * (Qx[i] - sigma * x[i]) + q[i]) * x[i];
+    } else {
+        if (n >= 4) for (; i <= n - 4; i += 4)
+            obj += (0.5 * Qx[i] + q[i]) * x[i] + (0.5 * Qx[i + 1] + q[i + 1]) * x[i + 1] + (0.5 * Qx[i + 2] + q[i + 2]) * x[i + 2] +
+                   (0.5 * Qx[i + 3] + q[i + 3]) * x[i + 3];
+        for (; i < n; i++) obj += (0.5 * Qx[i] + q[i]) * x[i];
+    }
+    return obj;
+}
 template <class T>
 __device__ __forceinline__ T *uni_ptr(T *p) {
     const unsigned long long v = (unsigned long long)p;
@@ -712,14 +752,18 @@ __device__ __forceinline__ T *uni_ptr(T *p) {
     return (T *)(((unsigned long long)hi << 32) | lo);
 }
 // ---- the whole solve of one QP by one workgroup ----------------------------------------------------------
-__global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, int count, QPDOSettings st, int klds_ok) {
+// LAT = 0: the batch kernel (held to 128 VGPRs so that two workgroups share a CU); LAT = 1: the latency variant for ONE workspace
+// (qdev_small_resident_solve): the same code with the whole register file of a CU's SIMDs to itself (no spills) -- same operations
+// in the same order, so the same bits.
+template <int LAT>
+__device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, const QPDOSettings &st, int klds_ok) {
     __shared__ double sm[32];
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
     // dynamic LDS: [xs: n][colbuf: n][tk: 2n][4n more for the four-column factorization][gbuf][d_s: m][rp_s: m+1][U], U = one region shared by the packed factor K
     // (if it fits) and the linesearch scratch (delta, alpha, sort keys, sort indices, flags).  The linesearch of a
     // pass runs after the pass's solve, so it may overwrite K: the factor is then rebuilt in the next pass instead
     // of being reused when the weights did not change -- the same bits, a little more work -- and the workgroup needs
     // ~67 KB instead of ~104 KB at n = 120, m = 360: two workgroups per CU instead of one.
-    extern __shared__ __attribute__((aligned(16))) double dyn[];
     if ((int)blockIdx.x >= count) return;
     // Every field of the item's descriptor is the same for all threads, but loaded from global memory it lands in VECTOR registers, and
     // so does every pointer derived from it (~45 of them are live across the solve loop: two thirds of the 128-VGPR budget).  Passing
@@ -731,6 +775,20 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
     UNI_PTR(Arp); UNI_PTR(Aci); UNI_PTR(Aval); UNI_PTR(Trp); UNI_PTR(Tci); UNI_PTR(Tval); UNI_PTR(Qrp); UNI_PTR(Qci); UNI_PTR(Qval);
     UNI_PTR(q); UNI_PTR(l); UNI_PTR(u); UNI_PTR(x0); UNI_PTR(y0); UNI_PTR(nv); UNI_PTR(mv); UNI_PTR(lsv); UNI_PTR(iv); UNI_PTR(tpos); UNI_PTR(K);
     UNI_PTR(sol_x); UNI_PTR(sol_y); UNI_PTR(cert_dx); UNI_PTR(cert_dy); UNI_PTR(prof);
+    // resident-mode extras (compiled out of the batch kernel: its register budget is spoken for)
+    SmallRes *Rg = nullptr; int resident = 0;
+    const double *rD = nullptr, *rDinv = nullptr, *rE = nullptr, *rEinv = nullptr; double *state_x = nullptr, *state_Qx = nullptr;
+    QPDOAmdTraceRec *trace = nullptr; long trace_cap = 0; double *out_x = nullptr, *out_y = nullptr; int mode = 0;
+    if constexpr (LAT) {
+        Rg = uni_ptr(Pg.res);
+        if (Rg) {
+            resident = 1;
+            rD = uni_ptr(Rg->rD); rDinv = uni_ptr(Rg->rDinv); rE = uni_ptr(Rg->rE); rEinv = uni_ptr(Rg->rEinv);
+            state_x = uni_ptr(Rg->state_x); state_Qx = uni_ptr(Rg->state_Qx); trace = uni_ptr(Rg->trace); trace_cap = Rg->trace_cap;
+            out_x = uni_ptr(Rg->out_x); out_y = uni_ptr(Rg->out_y);
+            mode = __builtin_amdgcn_readfirstlane(Rg->mode);
+        }
+    }
 #undef UNI_PTR
     P.c_const = Pg.c_const;
     const int n = P.n, m = P.m;
@@ -769,12 +827,24 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
     FOR_T(i, MV_COUNT * m) P.mv[i] = 0.0;
     FOR_T(i, 3 * m) P.iv[i] = 0;
     SYNC;
-    if (scaled) small_scale(P, (int)st.scaling, D, Dinv, E, Einv, tn, tm, sc_c, sc_cinv, sm);
+    if (scaled && !resident) small_scale(P, (int)st.scaling, D, Dinv, E, Einv, tn, tm, sc_c, sc_cinv, sm);
+    else if (scaled) {                              // resident: qpdo_setup's scaling (Ruiz + cost, scaling.c:24-91), as installed in the workspace
+        FOR_T(j, n) { D[j] = rD[j]; Dinv[j] = rDinv[j]; }
+        FOR_T(i, m) { E[i] = rE[i]; Einv[i] = rEinv[i]; }
+        sc_c = Rg->r_c; sc_cinv = Rg->r_cinv;
+        SYNC;
+    }
+    const bool ws_scaled = scaled;
 
     // ---- warm start (qpdo.c:217-299) + initialize_mu (iteration.c:98-122) ----
     double sigma = st.sigma_init;
+    if (LAT && mode == 2) {                         // the workspace's state, as qpdo_warm_start (mode 1) and any qpdo_update_* since left it
+        FOR_T(j, n) { x[j] = state_x[j]; xbar[j] = Rg->st_xbar[j]; Qx[j] = state_Qx[j]; Aty[j] = Rg->st_Aty[j]; }
+        FOR_T(i, m) { y[i] = Rg->st_y[i]; ybar[i] = Rg->st_ybar[i]; Ax[i] = Rg->st_Ax[i]; mu[i] = Rg->st_mu[i]; isq[i] = Rg->st_isq[i]; }
+        SYNC;
+    } else {
     if (P.x0) {
-        FOR_T(i, n) { double v = P.x0[i]; if (scaled) v = v * Dinv[i]; x[i] = v; xbar[i] = v; }
+        FOR_T(i, n) { double v = P.x0[i]; if (ws_scaled) v = v * Dinv[i]; x[i] = v; xbar[i] = v; }
         SYNC;
         spmv_rows(n, P.Qrp, P.Qci, P.Qval, x, Qdx);
         spmv_rows(m, P.Arp, P.Aci, P.Aval, x, Ax);
@@ -783,7 +853,7 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
         SYNC;
     }
     if (P.y0) {
-        FOR_T(i, m) { double v = P.y0[i]; if (scaled) { v = v * Einv[i]; v = v * sc_c; } y[i] = v; ybar[i] = v; }
+        FOR_T(i, m) { double v = P.y0[i]; if (ws_scaled) { v = v * Einv[i]; v = v * sc_c; } y[i] = v; ybar[i] = v; }
         SYNC;
         spmv_rows(n, P.Trp, P.Tci, P.Tval, y, Aty);
         SYNC;
@@ -797,6 +867,17 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
             double s = sqrt(v); isq[i] = 1.0 / s;
         }
         SYNC;
+    }
+    }
+    if (LAT && mode == 1) {                         // an explicit qpdo_warm_start: hand the state to the workspace and stop
+        FOR_T(j, n) { state_x[j] = x[j]; Rg->st_xbar[j] = xbar[j]; state_Qx[j] = Qx[j]; Rg->st_Aty[j] = Aty[j]; }
+        FOR_T(i, m) { Rg->st_y[i] = y[i]; Rg->st_ybar[i] = ybar[i]; Rg->st_Ax[i] = Ax[i]; Rg->st_mu[i] = mu[i]; Rg->st_isq[i] = isq[i]; }
+        if (threadIdx.x == 0) {
+            double obj = small_objective(n, prox, sigma, Qx, x, P.q);     // qpdo.c:257 (compute_objective on the warm-started x)
+            if (scaled) obj *= sc_cinv;
+            Rg->ws_objective = obj + P.c_const;
+        }
+        return;
     }
     const double isq_mu_min = 1 / sqrt(st.mu_min);
 
@@ -839,11 +920,18 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
             rpn = m1; rdn = m2; rpin = m3; rdin = m4;
             if (scaled) { rdn *= sc_cinv; rdin *= sc_cinv; }
         }
+        // per-pass trace record (the fields of the host loop's record, qpdo_api.c; resident mode only): lane 0, into pinned host memory
+        QPDOAmdTraceRec *tr = (LAT && trace && iter < trace_cap && threadIdx.x == 0) ? trace + iter : nullptr;
+        if (tr) {
+            tr->kind = 2; tr->n_active = 0; tr->n_enter = 0; tr->n_leave = 0; tr->factor_branch = -1; tr->lin_iters = 0; tr->tau = 0.0;
+            tr->res_prim = rpn; tr->res_dual = rdn; tr->res_prim_in = rpin; tr->res_dual_in = rdin; tr->sigma = sigma; tr->eps_in = eps_in;
+        }
         if ((rpn > SM_INFTY) || (rdn > SM_INFTY)) { status = QPDO_NON_CVX; break; }
         if ((rpn <= st.eps_abs) && (rdn <= st.eps_abs)) { status = QPDO_SOLVED; break; }
         const int inner_opt = (rpin <= eps_in) && (rdin <= eps_in);
         PH(PH_RESID);
         if (((iter > iter_old + 1) && inner_opt) || (iter == iter_old + st.inner_max_iter)) {
+            if (tr) tr->kind = 1;
             if (iter < iter_old + st.inner_max_iter) {
                 if (st.eps_prim_inf > 0) {           // termination.c:97-151
                     FOR_T(i, m) dy[i] = y[i] - ybar[i];
@@ -1021,13 +1109,15 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
             spmv_rows(n, P.Trp, P.Tci, P.Tval, dy, Atdy);
             SYNC;
             PH(PH_SPMV);
-            tau = small_linesearch(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf);
+            if constexpr (LAT) tau = small_linesearch_impl(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf);
+            else tau = small_linesearch(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf);
             lds_has_factor = 0;                      // the scratch above lives in the factor's LDS region
             PH(PH_LS);
             FOR_T(j, n) { x[j] = x[j] + tau * dx[j]; Qx[j] = Qx[j] + tau * Qdx[j]; Aty[j] = Aty[j] + tau * Atdy[j]; }
             FOR_T(i, m) { y[i] = y[i] + tau * dy[i]; Ax[i] = Ax[i] + tau * Adx[i]; }
             SYNC;
             newton++;
+            if (tr) { tr->kind = 0; tr->n_active = na; tr->n_enter = ne; tr->n_leave = nl; tr->factor_branch = branch; tr->tau = tau; }
             PH(PH_UPDATE);
         }
         if (timed) {                                  // qpdo.c:441-447: checked at the end of every pass, iter is not advanced
@@ -1043,20 +1133,10 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
     FOR_T(i, m) { if (scaled) { const double v = y[i] * sc_cinv; y[i] = v; P.sol_y[i] = v * E[i]; } else P.sol_y[i] = y[i]; }
     FOR_T(j, n) P.cert_dx[j] = dx[j];
     FOR_T(i, m) P.cert_dy[i] = dy[i];
+    if (LAT && state_x) { FOR_T(j, n) { state_x[j] = x[j]; state_Qx[j] = Qx[j]; out_x[j] = x[j]; } FOR_T(i, m) out_y[i] = y[i]; }
     SYNC;
     if (threadIdx.x == 0) {
-        double obj = 0; int i = 0;
-        if (prox) {
-            if (n >= 4) for (; i <= n - 4; i += 4)
-                obj += (0.5 * (Qx[i] - x[i] * sigma) + P.q[i]) * x[i] + (0.5 * (Qx[i + 1] - x[i + 1] * sigma) + P.q[i + 1]) * x[i + 1] +
-                       (0.5 * (Qx[i + 2] - x[i + 2] * sigma) + P.q[i + 2]) * x[i + 2] + (0.5 * (Qx[i + 3] - x[i + 3] * sigma) + P.q[i + 3]) * x[i + 3];
-            for (; i < n; i++) obj += (0.5 * (Qx[i] - sigma * x[i]) + P.q[i]) * x[i];
-        } else {
-            if (n >= 4) for (; i <= n - 4; i += 4)
-                obj += (0.5 * Qx[i] + P.q[i]) * x[i] + (0.5 * Qx[i + 1] + P.q[i + 1]) * x[i + 1] + (0.5 * Qx[i + 2] + P.q[i + 2]) * x[i + 2] +
-                       (0.5 * Qx[i + 3] + P.q[i + 3]) * x[i + 3];
-            for (; i < n; i++) obj += (0.5 * Qx[i] + P.q[i]) * x[i];
-        }
+        double obj = small_objective(n, prox, sigma, Qx, x, P.q);
         if (scaled) obj *= sc_cinv;
         obj += P.c_const;
         Pg.info.iterations = iter; Pg.info.oterations = oter;
@@ -1068,7 +1148,19 @@ __global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, i
         Pg.info.run_time = Pg.info.setup_time + Pg.info.solve_time;
         small_status(Pg.info, status);
         Pg.newton_passes = newton; Pg.factor_count = nfactor; (void)nrestore;
+        if constexpr (LAT) {
+            if (Rg) {
+                Rg->sigma_end = sigma; Rg->tau_end = tau;
+                Rg->ntrace = (status == QPDO_MAX_ITER_REACHED) ? iter : iter + 1;     // a pass that ended the loop by `break` left a record too
+            }
+        }
     }
+}
+__global__ __launch_bounds__(SM_THREADS, 4) void k_small_solve(SmallQP *probs, int count, QPDOSettings st, int klds_ok) {
+    small_solve_body<0>(probs, count, st, klds_ok);
+}
+__global__ __launch_bounds__(SM_THREADS, 2) void k_small_solve_lat(SmallQP *probs, int count, QPDOSettings st, int klds_ok) {
+    small_solve_body<1>(probs, count, st, klds_ok);
 }
 
 // ================================================================================================
@@ -1182,6 +1274,20 @@ static int pinned_reserve(char **buf, size_t *cap, size_t need) {
     *cap = want;
     return 0;
 }
+// dynamic LDS of a workgroup whose largest item has (nmax, mmax): the fixed part + the union region U (packed factor K if it fits,
+// else the linesearch scratch alone; the kernel's layout, k_small_solve).  klds_ok (optional out): 1 when K lives in LDS; passing
+// NULL sizes the K-in-global-memory layout.
+static const size_t SMALL_LDS_BUDGET = 160 * 1024 - 1024;                // static LDS: reduction scratch only
+static size_t small_lds_bytes(size_t nmax, size_t mmax, int *klds_ok) {
+    size_t lds = 8 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
+    const size_t kbytes = nmax * (nmax + 1) / 2 * 8;
+    size_t np2 = 1; while (np2 < 2 * mmax) np2 <<= 1;
+    size_t lsbytes = 2 * mmax * (8 + 8) + np2 * (8 + 4) + ((2 * mmax + 15) & ~(size_t)15);   // delta, alpha, keys, indices, flags
+    { const size_t gdots = 8 * (2 * (mmax / 4 + 4) + 2 * (nmax / 4 + 4)); if (gdots > lsbytes) lsbytes = gdots; }   // the group arrays of the four dot products live there too
+    const int ok = klds_ok && (lds + (kbytes > lsbytes ? kbytes : lsbytes) <= SMALL_LDS_BUDGET);
+    if (klds_ok) *klds_ok = ok;
+    return lds + ((ok && kbytes > lsbytes) ? kbytes : lsbytes);
+}
 static volatile double s_last_kernel_s = 0.0;   // (a statistic: written by whichever batch finished last; an aligned 8-byte store)
 //          // HIP-event duration of the last finished k_small_solve launch (bench.py's latency statement)
 
@@ -1279,15 +1385,10 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
     {
         size_t nmax = 1, mmax = 0;
         for (long i = 0; i < count; i++) { if (items[i].data->n > nmax) nmax = items[i].data->n; if (items[i].data->m > mmax) mmax = items[i].data->m; }
-        size_t lds = 8 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
-        const size_t kbytes = nmax * (nmax + 1) / 2 * 8;
-        size_t np2 = 1; while (np2 < 2 * mmax) np2 <<= 1;
-        size_t lsbytes = 2 * mmax * (8 + 8) + np2 * (8 + 4) + ((2 * mmax + 15) & ~(size_t)15);   // delta, alpha, keys, indices, flags
-        { const size_t gdots = 8 * (2 * (mmax / 4 + 4) + 2 * (nmax / 4 + 4)); if (gdots > lsbytes) lsbytes = gdots; }   // the group arrays of the four dot products live there too
-        const size_t budget = 160 * 1024 - 1024;                // static LDS: reduction scratch only
-        int klds_ok = (lds + (kbytes > lsbytes ? kbytes : lsbytes) <= budget) ? 1 : 0;
-        if (const char *kg = getenv("QPDO_SMALL_K_GLOBAL")) { if (atoi(kg)) klds_ok = 0; }      // occupancy experiments
-        lds += (klds_ok && kbytes > lsbytes) ? kbytes : lsbytes;
+        const size_t budget = SMALL_LDS_BUDGET;
+        int klds_ok = 0;
+        size_t lds = small_lds_bytes(nmax, mmax, &klds_ok);
+        if (const char *kg = getenv("QPDO_SMALL_K_GLOBAL")) { if (atoi(kg) && klds_ok) { klds_ok = 0; lds = small_lds_bytes(nmax, mmax, nullptr); } }      // occupancy experiments
         SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(budget)));
         if (const char *pad = getenv("QPDO_SMALL_LDS_MIN")) { const size_t v = (size_t)atol(pad); if (v > lds && v <= budget) lds = v; }   // occupancy experiments
         SHIP(hipEventRecord(S.ev0, S.stream));
@@ -1418,6 +1519,154 @@ int qdev_small_stream_wait(void *h, long ticket, double *kernel_seconds) {
     { std::lock_guard<std::mutex> lock(T->mu); S->busy = false; }
     return rc;
 }
+// ---- resident mode: qpdo_solve of ONE small workspace through the latency variant of the fused kernel ------------------------------
+// Everything the kernel reads per solve is already on the device (the workspace's own arrays); its descriptor and every output live in
+// pinned host memory that the kernel reads / writes directly: one launch + one stream synchronisation per qpdo_solve, no copies.
+struct SmallResident {
+    int device = 0; hipStream_t stream = nullptr; int n = 0, m = 0;
+    char *arena = nullptr;                             // device scratch of the one item: nv, mv, lsv, iv, tpos, K
+    struct HostBlock { SmallQP p; SmallRes r; } *hb = nullptr;      // pinned
+    double *hout = nullptr;                            // pinned: sol_x(n) sol_y(m) x(n) y(m) dx(n) dy(m)
+    QPDOAmdTraceRec *htrace = nullptr; long trace_cap = 0;           // pinned
+    size_t lds = 0; int klds_ok = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t o_nv = 0, o_mv = 0, o_lsv = 0, o_iv = 0, o_tpos = 0, o_K = 0;
+    double *h_x0 = nullptr, *h_y0 = nullptr;           // pinned copies of an explicit warm start's vectors (inside hout)
+    long long *dprof = nullptr;                        // QPDO_SMALL_PROF=1: in-kernel phase ticks
+};
+int qdev_small_resident_fits(int32_t n, int32_t m) {
+    if (n < 1 || n > SM_MAX_N || m < 0 || m > SM_MAX_M) return 0;
+    int ok = 0;
+    (void)small_lds_bytes((size_t)n, (size_t)m, &ok);
+    return ok;                                          // the packed factor must live in LDS: beyond that one workgroup is the wrong shape
+}
+void qdev_small_resident_destroy(void *h) {
+    SmallResident *R = (SmallResident *)h;
+    if (!R) return;
+    (void)hipSetDevice(R->device);
+    if (R->stream) (void)hipStreamSynchronize(R->stream);
+    if (R->arena) (void)hipFree(R->arena);
+    if (R->hb) (void)hipHostFree(R->hb);
+    if (R->hout) (void)hipHostFree(R->hout);
+    if (R->htrace) (void)hipHostFree(R->htrace);
+    if (R->dprof) (void)hipFree(R->dprof);
+    if (R->ev0) (void)hipEventDestroy(R->ev0);
+    if (R->ev1) (void)hipEventDestroy(R->ev1);
+    delete R;
+}
+void *qdev_small_resident_create(const QdevSmallView *v, long trace_cap) {
+    int rc = 0;
+    SmallResident *R = new SmallResident();
+    R->device = v->device; R->stream = (hipStream_t)v->stream; R->n = v->n; R->m = v->m;
+    const size_t n = (size_t)v->n, m = (size_t)v->m;
+    size_t total = 0;
+    auto reserve = [&](size_t bytes) { size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; };
+    int nnzA = 0;
+    SHIP(hipSetDevice(R->device));
+    SHIP(hipMemcpy(&nnzA, v->Arp + m, sizeof(int), hipMemcpyDeviceToHost));
+    R->o_nv = reserve((size_t)NV_COUNT * n * 8); R->o_mv = reserve((size_t)MV_COUNT * m * 8 + 8); R->o_lsv = reserve(4 * m * 8 + 8);
+    R->o_iv = reserve(3 * m * 4 + 4); R->o_tpos = reserve((size_t)nnzA * 4 + 4); R->o_K = reserve(n * n * 8);
+    SHIP(hipMalloc((void **)&R->arena, total));
+    SHIP(hipHostMalloc((void **)&R->hb, sizeof(*R->hb), hipHostMallocDefault));
+    SHIP(hipHostMalloc((void **)&R->hout, (4 * n + 4 * m + 8) * 8, hipHostMallocDefault));
+    R->h_x0 = R->hout + (3 * n + 3 * m + 6); R->h_y0 = R->h_x0 + n;
+    if (trace_cap < 1) trace_cap = 1;
+    SHIP(hipHostMalloc((void **)&R->htrace, (size_t)trace_cap * sizeof(QPDOAmdTraceRec), hipHostMallocDefault));
+    R->trace_cap = trace_cap;
+    SHIP(hipEventCreate(&R->ev0)); SHIP(hipEventCreate(&R->ev1));
+    R->lds = small_lds_bytes(n, m, &R->klds_ok);
+    if (!R->klds_ok) { snprintf(s_err, sizeof(s_err), "resident fused solve: the packed factor of n = %d does not fit in LDS", v->n); rc = -1; goto done; }
+    SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve_lat), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS_BUDGET));
+done:
+    if (rc) { qdev_small_resident_destroy(R); return nullptr; }
+    return R;
+}
+// fills the pinned descriptor of the one item for a launch in `mode` (SmallRes)
+static void resident_fill(SmallResident *R, const QdevSmallView *v, int mode, double c_const) {
+    const size_t n = (size_t)R->n, m = (size_t)R->m;
+    SmallQP &p = R->hb->p; SmallRes &r = R->hb->r;
+    double *o = R->hout;
+    double *h_solx = o, *h_soly = h_solx + n, *h_x = h_soly + m + 1, *h_y = h_x + n, *h_dx = h_y + m + 1, *h_dy = h_dx + n;
+    memset(&p, 0, sizeof(p)); memset(&r, 0, sizeof(r));
+    p.n = (int)n; p.m = (int)m; p.c_const = c_const;
+    p.Arp = v->Arp; p.Aci = v->Aci; p.Aval = const_cast<double *>(v->Aval);            // (read only here: the kernel's Ruiz phase, the one writer, is skipped)
+    p.Trp = v->Trp; p.Tci = v->Tci; p.Tval = const_cast<double *>(v->Tval);
+    p.Qrp = v->Qrp; p.Qci = v->Qci; p.Qval = const_cast<double *>(v->Qval);
+    p.q = const_cast<double *>(v->q); p.l = const_cast<double *>(v->l); p.u = const_cast<double *>(v->u);
+    p.nv = (double *)(R->arena + R->o_nv); p.mv = (double *)(R->arena + R->o_mv); p.lsv = (double *)(R->arena + R->o_lsv);
+    p.iv = (int *)(R->arena + R->o_iv); p.tpos = (int *)(R->arena + R->o_tpos); p.K = (double *)(R->arena + R->o_K);
+    p.sol_x = h_solx; p.sol_y = h_soly; p.cert_dx = h_dx; p.cert_dy = h_dy;
+    p.res = &R->hb->r;
+    p.prof = R->dprof;
+    r.mode = mode;
+    r.rD = v->D; r.rDinv = v->Dinv; r.rE = v->E; r.rEinv = v->Einv; r.r_c = v->c; r.r_cinv = v->cinv;
+    r.state_x = v->st_x; r.state_Qx = v->st_Qx; r.st_xbar = v->st_xbar; r.st_Aty = v->st_Aty;
+    r.st_y = v->st_y; r.st_ybar = v->st_ybar; r.st_Ax = v->st_Ax; r.st_mu = v->st_mu; r.st_isq = v->st_isq;
+    r.out_x = h_x; r.out_y = h_y;
+    r.trace = R->htrace; r.trace_cap = R->trace_cap;
+}
+int qdev_small_resident_warm_start(void *h, const QdevSmallView *v, const void *settings_, const double *x_ws, const double *y_ws, double c_const,
+                                   double *objective) {
+    int rc = 0;
+    SmallResident *R = (SmallResident *)h;
+    const QPDOSettings *settings = (const QPDOSettings *)settings_;
+    const size_t n = (size_t)R->n, m = (size_t)R->m;
+    SHIP(hipSetDevice(R->device));
+    resident_fill(R, v, 1, c_const);
+    if (x_ws) { memcpy(R->h_x0, x_ws, n * 8); R->hb->p.x0 = R->h_x0; }         // pinned copies: the caller may release its vectors on return
+    if (y_ws && m) { memcpy(R->h_y0, y_ws, m * 8); R->hb->p.y0 = R->h_y0; }
+    hipLaunchKernelGGL(k_small_solve_lat, dim3(1), dim3(SM_THREADS), R->lds, R->stream, &R->hb->p, 1, *settings, R->klds_ok);
+    SHIP(hipGetLastError());
+    SHIP(hipStreamSynchronize(R->stream));
+    *objective = R->hb->r.ws_objective;
+done:
+    return rc;
+}
+int qdev_small_resident_solve(void *h, const QdevSmallView *v, const void *settings_, int from_state, double c_const, QdevSmallResult *out) {
+    int rc = 0;
+    SmallResident *R = (SmallResident *)h;
+    const QPDOSettings *settings = (const QPDOSettings *)settings_;
+    const size_t n = (size_t)R->n, m = (size_t)R->m;
+    SmallQP &p = R->hb->p; SmallRes &r = R->hb->r;
+    double *o = R->hout;
+    double *h_solx = o, *h_soly = h_solx + n, *h_x = h_soly + m + 1, *h_y = h_x + n, *h_dx = h_y + m + 1, *h_dy = h_dx + n;
+    const char *pf = getenv("QPDO_SMALL_PROF");
+    const bool prof = pf && !strcmp(pf, "1");
+    SHIP(hipSetDevice(R->device));
+    if (settings->max_iter > R->trace_cap && R->trace_cap < (1L << 20)) {            // grow the trace with max_iter (bounded: 1 M records = 104 MB)
+        long cap = settings->max_iter < (1L << 20) ? (long)settings->max_iter : (1L << 20);
+        SHIP(hipStreamSynchronize(R->stream));
+        (void)hipHostFree(R->htrace); R->htrace = nullptr; R->trace_cap = 0;
+        SHIP(hipHostMalloc((void **)&R->htrace, (size_t)cap * sizeof(QPDOAmdTraceRec), hipHostMallocDefault));
+        R->trace_cap = cap;
+    }
+    if (prof && !R->dprof) SHIP(hipMalloc((void **)&R->dprof, PH_COUNT * sizeof(long long)));
+    if (R->dprof) SHIP(hipMemsetAsync(R->dprof, 0, PH_COUNT * sizeof(long long), R->stream));
+    resident_fill(R, v, from_state ? 2 : 0, c_const);
+    if (!prof) p.prof = nullptr;
+    SHIP(hipEventRecord(R->ev0, R->stream));
+    hipLaunchKernelGGL(k_small_solve_lat, dim3(1), dim3(SM_THREADS), R->lds, R->stream, &R->hb->p, 1, *settings, R->klds_ok);
+    SHIP(hipGetLastError());
+    SHIP(hipEventRecord(R->ev1, R->stream));
+    SHIP(hipStreamSynchronize(R->stream));
+    { float ms = 0.f; out->kernel_seconds = (hipEventElapsedTime(&ms, R->ev0, R->ev1) == hipSuccess) ? (double)ms * 1e-3 : 0.0; }
+    if (prof) {
+        long long hpf[PH_COUNT];
+        SHIP(hipMemcpy(hpf, R->dprof, sizeof(hpf), hipMemcpyDeviceToHost));
+        static const char *nm[PH_COUNT] = {"resid", "outer", "prep", "assemble", "factor", "solve", "spmv", "linesearch", "update", "(ls:dots", "ls:sort", "ls:jsum", "ls:walk)"};
+        fprintf(stderr, "[qpdo_small resident prof] n=%d m=%d, %ld passes, %ld factorizations, kernel %.3f ms; us:", R->n, R->m, (long)p.info.iterations, p.factor_count, out->kernel_seconds * 1e3);
+        for (int k = 0; k < PH_COUNT; k++) fprintf(stderr, " %s=%.0f", nm[k], hpf[k] * 1e-2);
+        fprintf(stderr, "\n");
+    }
+    *(QPDOInfo *)out->info = p.info;
+    out->newton_passes = p.newton_passes; out->factor_count = p.factor_count;
+    out->ntrace = r.ntrace < R->trace_cap ? r.ntrace : R->trace_cap; out->trace = R->htrace;
+    out->sol_x = h_solx; out->sol_y = h_soly; out->x = h_x; out->y = h_y; out->dx = h_dx; out->dy = h_dy;
+    out->sigma_end = r.sigma_end; out->tau_end = r.tau_end;
+done:
+    return rc;
+}
+
 void qdev_small_stream_destroy(void *h) {
     SmallStream *T = (SmallStream *)h;
     if (!T) return;

@@ -94,7 +94,7 @@ class Stats(C.Structure):
                 ("schur_passes", C.c_long), ("lowrank_solves", C.c_long), ("lowrank_cols", C.c_long), ("lowrank_sweeps", C.c_long),
                 ("lowrank_rejects", C.c_long), ("pcg_soft_accepts", C.c_long), ("collectives", C.c_long), ("inner_solves", C.c_long),
                 ("inner_steps", C.c_long), ("inner_collectives", C.c_long), ("chain_fallbacks", C.c_long),
-                ("pcg_max_relres", C.c_double), ("pcg_dense_fallbacks", C.c_long)]
+                ("pcg_max_relres", C.c_double), ("pcg_dense_fallbacks", C.c_long), ("fused_solves", C.c_long), ("fused_kernel_s", C.c_double)]
 
 
 API_SYMBOLS = ["qpdo_set_default_settings", "qpdo_setup", "qpdo_warm_start", "qpdo_solve", "qpdo_update_settings",
