@@ -84,7 +84,7 @@ enum { MV_Y = 0, MV_YBAR, MV_AX, MV_MU, MV_ISQ, MV_W, MV_RP, MV_RPOLD, MV_RPI, M
 
 // diagnostic phase timer: lane 0 adds wall-clock ticks (100 MHz) to a buffer no other code reads
 #define PH(k) do { if (P.prof && threadIdx.x == 0) { const long long t_ = wall_clock64(); P.prof[k] += t_ - tph; tph = t_; } } while (0)
-enum { PH_RESID = 0, PH_OUTER, PH_PREP, PH_ASM, PH_FACTOR, PH_SOLVE, PH_SPMV, PH_LS, PH_UPDATE, PH_LS_DOTS, PH_LS_SORT, PH_LS_JSUM, PH_LS_WALK, PH_COUNT };   // (the last four: inside PH_LS)
+enum { PH_RESID = 0, PH_OUTER, PH_PREP, PH_ASM, PH_FACTOR, PH_SOLVE, PH_SPMV, PH_LS, PH_UPDATE, PH_LS_DOTS, PH_LS_SORT, PH_LS_JSUM, PH_LS_WALK, PH_CYC /* shader cycles of the solve loop (s_memtime) */, PH_WALL /* its 100 MHz ticks */, PH_COUNT };   // (the last four: inside PH_LS)
 #define FOR_T(i, N) for (int i = threadIdx.x; i < (N); i += blockDim.x)
 #define SYNC __syncthreads()
 
@@ -890,6 +890,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
     double rpn = 0, rdn = 0, rpin = 0, rdin = 0;
     long long tph = P.prof ? wall_clock64() : 0;
     const long long t_solve = wall_clock64();
+    const long long cyc0 = P.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
     for (iter = 0; iter < st.max_iter; iter++) {
         // outer + inner residuals (iteration.c:30-93)
         FOR_T(i, m) {
@@ -1128,6 +1129,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
         }
     }
     if (status == QPDO_UNSOLVED) status = QPDO_MAX_ITER_REACHED;
+    if (P.prof && threadIdx.x == 0) { P.prof[PH_CYC] = (long long)__builtin_amdgcn_s_memtime() - cyc0; P.prof[PH_WALL] = wall_clock64() - t_solve; }
     // store_solution (termination.c:82-92) + objective (iteration.c:185-221)
     FOR_T(j, n) P.sol_x[j] = scaled ? x[j] * D[j] : x[j];
     FOR_T(i, m) { if (scaled) { const double v = y[i] * sc_cinv; y[i] = v; P.sol_y[i] = v * E[i]; } else P.sol_y[i] = y[i]; }
@@ -1424,7 +1426,7 @@ static int slot_finish(SmallSlot &S) {
         SHIP(hipMemcpy(hpf.data(), S.dprof, hpf.size() * sizeof(long long), hipMemcpyDeviceToHost));
         long best = 0; long long bt = -1;
         for (long i = 0; i < count; i++) { long long t = 0; for (int k = 0; k < PH_COUNT; k++) t += hpf[(size_t)i * PH_COUNT + k]; if (t > bt) { bt = t; best = i; } }
-        static const char *nm[PH_COUNT] = {"resid", "outer", "prep", "assemble", "factor", "solve", "spmv", "linesearch", "update", "(ls:dots", "ls:sort", "ls:jsum", "ls:walk)"};
+        static const char *nm[PH_COUNT] = {"resid", "outer", "prep", "assemble", "factor", "solve", "spmv", "linesearch", "update", "(ls:dots", "ls:sort", "ls:jsum", "ls:walk)", "cycles", "ticks"};
         fprintf(stderr, "[qpdo_small prof] item %ld, %ld passes, ticks(100MHz):", best, (long)S.hp[(size_t)best].info.iterations);
         for (int k = 0; k < PH_COUNT; k++) fprintf(stderr, " %s=%.1fms", nm[k], hpf[(size_t)best * PH_COUNT + k] * 1e-5);
         fprintf(stderr, "\n");
@@ -1653,9 +1655,10 @@ int qdev_small_resident_solve(void *h, const QdevSmallView *v, const void *setti
     if (prof) {
         long long hpf[PH_COUNT];
         SHIP(hipMemcpy(hpf, R->dprof, sizeof(hpf), hipMemcpyDeviceToHost));
-        static const char *nm[PH_COUNT] = {"resid", "outer", "prep", "assemble", "factor", "solve", "spmv", "linesearch", "update", "(ls:dots", "ls:sort", "ls:jsum", "ls:walk)"};
-        fprintf(stderr, "[qpdo_small resident prof] n=%d m=%d, %ld passes, %ld factorizations, kernel %.3f ms; us:", R->n, R->m, (long)p.info.iterations, p.factor_count, out->kernel_seconds * 1e3);
-        for (int k = 0; k < PH_COUNT; k++) fprintf(stderr, " %s=%.0f", nm[k], hpf[k] * 1e-2);
+        static const char *nm[PH_COUNT] = {"resid", "outer", "prep", "assemble", "factor", "solve", "spmv", "linesearch", "update", "(ls:dots", "ls:sort", "ls:jsum", "ls:walk)", "", ""};
+        fprintf(stderr, "[qpdo_small resident prof] n=%d m=%d, %ld passes, %ld factorizations, kernel %.3f ms, in-kernel clock %.0f MHz; us:", R->n, R->m, (long)p.info.iterations, p.factor_count,
+                out->kernel_seconds * 1e3, hpf[PH_WALL] > 0 ? 100.0 * (double)hpf[PH_CYC] / (double)hpf[PH_WALL] : 0.0);
+        for (int k = 0; k < PH_CYC; k++) fprintf(stderr, " %s=%.0f", nm[k], hpf[k] * 1e-2);
         fprintf(stderr, "\n");
     }
     *(QPDOInfo *)out->info = p.info;
