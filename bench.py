@@ -53,7 +53,7 @@ os.environ["QPDO_FIX_STATUS_RESET"] = "1"
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
 C3_COUNT = 4096           # BASELINE.json configs[2]
-MFMA_PROFILE = "r02_c2_dense_mfma_util_wide.json"   # (re-collected whenever k_ldl_syrk changes)
+MFMA_PROFILE = "r02_c2_dense_mfma_util_wide.json"   # (re-collected whenever k_ldl_syrk changes; unchanged since round 2)
 PMC_PROFILE = "r03_pmc_schur_inner_c4.json"     # HBM-traffic counters of the dominant kernel (tools/pmc_collect.sh writes it)
 
 
@@ -610,6 +610,10 @@ def main():
             live = ac_bytes / ac_n
             if ent is not None and ent.get("alg_bytes_per_launch_avg") and abs(ent["alg_bytes_per_launch_avg"] - live) <= 0.02 * live:
                 roof["traffic"] = ent["traffic_bytes_avg"]
+                # the bytes the kernel really moved over the live launch time, beside `achieved` (the ALGORITHMIC 12 B per nonzero over the
+                # same time): the kernel streams 16-bit slab-local column indices, 10 B per nonzero, so this figure is the lower one
+                roof["achieved_traffic_GBs"] = ent["traffic_bytes_avg"] / (ac_time / ac_n) / 1e9
+                roof["achieved_traffic_frac_of_achievable_6300GBs"] = roof["achieved_traffic_GBs"] / 6300.0
                 roof["traffic_age"] = pin.get("commit")
                 roof["traffic_source"] = ("profiles/%s (collected at commit %s): 2*FETCH_SIZE + WRITE_SIZE averaged over the %d real launches of this "
                                           "kernel in separate rocprofv3 --pmc passes over this command; its launch geometry (%.1f MB algorithmic per "
@@ -675,6 +679,22 @@ def main():
             out["cpu_baseline"] = cpu_baseline_single(prob, a.cpu_seconds, "direct" if cfg["n"] <= 20000 else "pcg")
         except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU line
             out["cpu_baseline"] = dict(value=None, unit="newton_iters/s", cores=host_cores(), kind="port", sample="failed: %r" % (e,))
+        if a.workload == "C4":
+            # The sample above is the first ~25 s of the oracle's solve: its cheapest passes.  The WHOLE solve of this instance by the
+            # oracle is on record (tests/golden/big_C4_full.npz, written by tests/golden/make_golden_big.py on the build container;
+            # log: profiles/r03_oracle_C4_full_run.log): it is the figure that compares with time_to_eps_s.
+            try:
+                import numpy as np
+                meta = json.loads(str(np.load(os.path.join(ROOT, "tests", "golden", "big_C4_full.npz"))["meta"]))
+                npass, sec = meta["info"]["newton_passes"], meta["oracle_seconds"]
+                out["cpu_baseline"]["full_solve"] = dict(
+                    value=npass / sec, unit="newton_iters/s", seconds=sec, newton_passes=npass, cg_iters=meta.get("oracle_lin_iters"),
+                    cores=meta.get("threads"), kind="port", measured="offline, on the build container (not on this host, not in this run)",
+                    note="the complete cold-start solve of this same instance by the oracle (Jacobi-PCG on the matrix-free Newton operator, compact "
+                         "32-bit copies, %s threads): %d Newton passes in %.0f s (setup included); the late passes need 1000-29000 CG iterations each, "
+                         "which is why the whole solve is ~75x slower per pass than the sampled early passes" % (meta.get("threads"), npass, sec))
+            except Exception as e:
+                out["cpu_baseline"]["full_solve"] = dict(error=repr(e))
     if rank == 0 and world == 1 and schur_passes and not a.no_mixed_extra:
         # Informational extra, NOT part of `value`: the same solve with the opt-in fp32 copy of the inner preconditioner's
         # matrix values (QPDO_PCG_INNER_F32=1; every vector, accumulation and the outer CG on the exact K stay fp64).

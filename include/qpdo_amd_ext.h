@@ -7,7 +7,9 @@
  *
  * Environment variables read once per qpdo_setup:
  *   QPDO_DEVICE      HIP device ordinal (default: LOCAL_RANK if set, else 0)
- *   QPDO_LINSOLVE    "pcg" | "dense" | "auto" (default auto: dense LDL' for n <= QPDO_DENSE_MAX_N = 12288)
+ *   QPDO_LINSOLVE    "pcg" | "dense" | "auto" (default auto: dense LDL' for n <= QPDO_DENSE_MAX_N = 12288; the dense solver accepts
+ *                    n <= 40000 -- its assembly tiles the LDS accumulator, QPDO_DENSE_ASM_TILE rows at a time -- and is also the rescue of
+ *                    a PCG solve that cannot converge up to that order)
  *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change, "1": low-rank update of the kept dense factor (default: from n = 2560 up)
  *   QPDO_DENSE_LOOKAHEAD "0": factor on one stream, "1": overlap the next panel with the trailing update (default: from n = 7000 up)
  *   QPDO_DENSE_RESERVE_CUS  CUs left out of the trailing-update stream's mask (default 32; 0 = no mask)
@@ -78,7 +80,7 @@ typedef struct {
     long   chain_fallbacks; /* dense triangular solves redone with the stepwise kernels (dense LDL')                  */
     double pcg_max_relres;  /* largest ||r||/||rhs|| a PCG solve of the last qpdo_solve ended with (tolerance QPDO_PCG_TOL)      */
     long   pcg_dense_fallbacks; /* PCG solves that could not converge (relative residual > 1e-8: e.g. settings->proximal = 0 on a singular
-                             * Q + A'DA) and were redone by the dense LDL' solver, which the rest of that qpdo_solve then keeps (n <= 18000) */
+                             * Q + A'DA) and were redone by the dense LDL' solver, which the rest of that qpdo_solve then keeps (n <= 40000) */
     long   fused_solves;    /* qpdo_solve calls of this workspace that ran as ONE launch of the fused small-problem kernel (then linsolve = 2:
                              * in-LDS natural-order LDL' in the oracle's operation order, factor_count = its factorizations)                  */
     double fused_kernel_s;  /* HIP-event duration of that launch in the last qpdo_solve (0 if it took the generic path)                     */

@@ -421,7 +421,33 @@ QPDOWorkspace *qpdo_setup(const QPDOData *data, const QPDOSettings *settings) {
     work->chol->reset_newton = 1;
     work->chol->fix_status_reset = env_int("QPDO_FIX_STATUS_RESET", 0);
 
-    {   /* matrices to the device */
+    int on_device = 0;
+    {   /* matrices to the device.  One GPU (the default): the caller's CSC arrays are uploaded as they are -- they ARE CSR(A') -- and
+         * CSR(A) and the full symmetric CSR(Q) are built on the device (qdev_create_csc: the same arrays, bit for bit, that the host
+         * conversions below produce; QPDO_SETUP_HOST=1 keeps those).  A row-partitioned workspace cuts its slices on the host. */
+        QdevDist dd0;
+        pthread_mutex_lock(&g_dist_mu); dd0 = g_dist; pthread_mutex_unlock(&g_dist_mu);
+        if (dd0.world <= 1 && !dd0.force && !env_int("QPDO_SETUP_HOST", 0)) {
+            const int prof = env_int("QPDO_SETUP_PROF", 0);
+            const double t0 = wall_now();
+            int ndev = qdev_device_count();
+            if (ndev <= 0) { QPDO_EPRINT("no HIP device available (this library has no CPU path)"); goto fail; }
+            int device = env_int("QPDO_DEVICE", env_int("LOCAL_RANK", 0)) % ndev;
+            const cholmod_sparse *A = data->A, *Q = data->Q;
+            QdevCsc a = {(int32_t)A->nrow, (int32_t)A->ncol, idx_at(A->p, A->itype, (int64_t)A->ncol), A->itype, A->p, A->i, (const double *)A->x, 0};
+            QdevCsc qq = {(int32_t)Q->nrow, (int32_t)Q->ncol, idx_at(Q->p, Q->itype, (int64_t)Q->ncol), Q->itype, Q->p, Q->i, (const double *)Q->x, Q->stype};
+            if (qdev_create_csc(&work->chol->dev, device, (int32_t)n, (int32_t)m, &a, &qq, work->data->q, work->data->l, work->data->u)) {
+                QPDO_EPRINT("device backend: %s", qdev_last_error()); goto fail;
+            }
+            if (prof) fprintf(stderr, "[setup] device create     %.3f s (upload of the CSC arrays, transpositions and slab tables on the device)\n", wall_now() - t0);
+            const char *ls = getenv("QPDO_LINSOLVE");
+            int mode = -1;
+            if (ls && !strcmp(ls, "pcg")) mode = 0; else if (ls && !strcmp(ls, "dense")) mode = 1;
+            qdev_configure(work->chol->dev, mode, env_double("QPDO_PCG_TOL", 0.0), env_int("QPDO_PCG_MAXIT", 0));
+            on_device = 1;
+        }
+    }
+    if (!on_device) {   /* host conversions (row-partitioned workspaces; QPDO_SETUP_HOST=1) */
         HostCsr Ar = {0}, At = {0}, Qf = {0};
         const int prof = env_int("QPDO_SETUP_PROF", 0);
         double t0 = wall_now();

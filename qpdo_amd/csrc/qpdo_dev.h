@@ -63,6 +63,16 @@ const char *qdev_last_error(void);
 int qdev_create(QpdoDev **out, int device, int32_t n, int32_t m,
                 const QdevCsr *Ar, const QdevCsr *At, const QdevCsr *Qf,
                 const double *q, const double *l, const double *u);
+/* The same from the caller's CSC arrays (cholmod_sparse, int32 or int64 indices): they are uploaded as they are -- the CSC arrays of A ARE
+ * CSR(A') -- and CSR(A) and the full symmetric CSR(Q) are built on the device (stable radix transposition, dev/transpose.inc).  One GPU. */
+typedef struct {
+    int32_t nrows, ncols; int64_t nnz;
+    int itype;            /* 0: int32 indices, 2: int64 (CHOLMOD_INT / CHOLMOD_LONG) */
+    const void *p, *i; const double *x;
+    int stype;            /* Q: -1 lower stored, +1 upper stored, 0 full; A: 0 */
+} QdevCsc;
+int qdev_create_csc(QpdoDev **out, int device, int32_t n, int32_t m, const QdevCsc *A, const QdevCsc *Q,
+                    const double *q, const double *l, const double *u);
 /* row partition of one large QP (one process per GPU).  fn != NULL: host-callback all-reduce (tests);
  * fn == NULL and world > 1: RCCL with the 128-byte unique id of rank 0. */
 typedef void (*qdev_allreduce_fn)(void *ctx, double *buf, long count, int op /*0 sum, 1 max*/);

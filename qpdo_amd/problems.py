@@ -62,6 +62,28 @@ def random_qp(seed, n, m, density, n_eq=0):
     return dict(n=n, m=m, Q=Q, Qstype=-1, A=A, q=q, l=l, u=u, c=0.0, seed=int(seed))
 
 
+def banded_qp(seed, n, n_rate=None, q_scale=1.0, box=1.0, rate=0.05, q_reg=0.0):
+    """A chain-structured (MPC / spline-type) QP: Q = second-difference operator (tridiagonal, singular along constants unless
+    q_reg > 0), constraints = n box rows -box <= x_i <= box followed by n_rate rate rows |x_{i+1} - x_i| <= rate.  The Newton matrix
+    Q + sigma I + A'DA is tridiagonal: trivial for a direct factorization (the reference: CHOLMOD), but its Jacobi-preconditioned
+    condition number is ~ 4 / sigma, so a diagonally preconditioned CG stalls late in a solve -- the case that needs a direct solver."""
+    rng = np.random.default_rng(seed)
+    n_rate = n - 1 if n_rate is None else int(n_rate)
+    main = np.full(n, 2.0 + q_reg); main[0] = main[-1] = 1.0 + q_reg
+    Q = sp.diags([main, -np.ones(n - 1)], [0, -1], format="csc")            # lower triangle
+    rows = np.concatenate([np.arange(n), n + np.arange(n_rate), n + np.arange(n_rate)])
+    cols = np.concatenate([np.arange(n), np.arange(n_rate), np.arange(n_rate) + 1])
+    vals = np.concatenate([np.ones(n), -np.ones(n_rate), np.ones(n_rate)])
+    m = n + n_rate
+    A = sp.csc_matrix((vals, (rows, cols)), shape=(m, n))
+    A.sort_indices()
+    t = np.linspace(0.0, 1.0, n)
+    q = q_scale * (np.sin(6.0 * np.pi * t) * 0.02 + 0.002 * rng.standard_normal(n))
+    l = np.concatenate([np.full(n, -box), np.full(n_rate, -rate)])
+    u = np.concatenate([np.full(n, box), np.full(n_rate, rate)])
+    return dict(n=n, m=m, Q=Q, Qstype=-1, A=A, q=q, l=l, u=u, c=0.0, seed=int(seed))
+
+
 def config_qp(name, index=0):
     cfg = CONFIGS[name]
     seed = BASE_SEED + 1000 * (list(CONFIGS).index(name) + 1) + index

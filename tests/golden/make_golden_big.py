@@ -44,6 +44,12 @@ CASES = {
     # the whole solve of the metric's configuration (round 3: the oracle's PCG operator streams compact 32-bit copies,
     # bit-identical to its plain loops -- tests/test_oracle_specs.py -- which makes the 65 passes a matter of hours)
     "C4_full": (dict(cfg="C4", index=0), dict()),
+    # round 4: a chain-structured (banded) instance ABOVE the former limit of the dense direct solver (n <= 18000, an LDS accumulator):
+    # the forced dense path, the default PCG path and the PCG -> dense rescue are all compared with this record
+    "banded_20k": (dict(banded=(1, 20_000, {})), dict()),
+    # the same structure without the proximal term (a slightly regularised Q keeps K definite): proximal = 0 drops the absolute stopping
+    # rule of the PCG and is where Jacobi-PCG solves have failed before (tests/test_gpu_sweep.py instance 1358)
+    "banded_20k_noprox": (dict(banded=(2, 20_000, dict(q_reg=1e-4))), dict(proximal=0)),
 }
 LINSOLVE = {"C4_first16": "pcg", "C4_first32": "pcg", "C4_first40": "pcg", "C4_full": "pcg"}
 TRACE_FIELDS = ["kind", "n_active", "n_enter", "n_leave", "factor_branch", "tau", "res_prim", "res_dual",
@@ -53,6 +59,9 @@ TRACE_FIELDS = ["kind", "n_active", "n_enter", "n_leave", "factor_branch", "tau"
 def make_problem(spec):
     if "cfg" in spec:
         return problems.config_qp(spec["cfg"], spec["index"])
+    if "banded" in spec:
+        seed, n, kw = spec["banded"]
+        return problems.banded_qp(seed, n, **kw)
     seed, n, m, dens, neq = spec["rand"]
     return problems.random_qp(seed, n, m, dens, neq)
 

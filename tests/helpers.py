@@ -22,7 +22,11 @@ KKT_ATOL = 1e-10         # |KKT residual - reference KKT residual| <= KKT_ATOL
 # the Newton matrix has weights 1/mu up to 1e9 against sigma = 1e-7, and both the direction and the breakpoint root
 # inherit eps * kappa.
 TAU_RTOL = 1e-8          # |tau - tau_ref| <= TAU_RTOL * max(1, |tau_ref|)   dense LDL' (measured max 1.4e-9: full-size C2, pass 44)
-TAU_RTOL_PCG = 1e-7      # PCG to a 1e-12 relative residual                  (measured max 1.1e-8)
+TAU_RTOL_PCG = 1e-7      # PCG to a 1e-12 relative residual                  (measured max 1.1e-8 over everything but the case below)
+TAU_RTOL_PCG_C4_FULL = 3e-7  # the complete C4 record only: measured 5.7e-8 on ONE late pass (weights 1/mu up to 1e9 against sigma = 1e-7:
+                         # kappa(K) > 1e12, the step length inherits eps * kappa from either implementation's direction); 5x that, so that a
+                         # compiler or clock change cannot turn the headline fixture red for no algorithmic reason.  Every other pass of that
+                         # record, and every other fixture, stays on TAU_RTOL_PCG.
 NORM_RTOL = 1e-8         # the four residual norms of a pass: |v - v_ref| <= NORM_RTOL * |v_ref| + NORM_ATOL
 NORM_RTOL_PCG = 1e-6
 NORM_ATOL = 1e-9         # a residual is a difference of O(1..100) quantities, its error is absolute (measured max 2.7e-10)
@@ -43,6 +47,9 @@ def golden_problem(spec):
         return problems.infeasibility_kat(spec["kat"])
     if "cfg" in spec:
         return problems.config_qp(spec["cfg"], spec["index"])
+    if "banded" in spec:
+        seed, n, kw = spec["banded"]
+        return problems.banded_qp(seed, n, **kw)
     seed, n, m, dens, neq = spec["rand"]
     return problems.random_qp(seed, n, m, dens, neq)
 

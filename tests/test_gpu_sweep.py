@@ -283,3 +283,44 @@ def test_schur_mode_on_mid_size_lp_like_instances(qdiag, gpu_required, monkeypat
     assert same_trace_counts(r["trace"], to)
     if oi["status_val"] == 1:
         assert close_vec(r["x"], ox, 1e-7) and close_vec(r["y"], oy, 1e-7)
+
+
+def test_whole_c3_batch_of_4096_at_reference_default_settings(gpu_required):
+    """BASELINE.json configs[2] at FULL size through the path bench.py measures: 4096 MPC-sized QPs (n = 120, m = 360, 120 equality rows),
+    one fused-kernel launch, the reference's default settings (max_iter = 10000: the handful of instances that stall just above eps_abs in
+    the reference algorithm itself run all 10000 passes).  Every item: a status the reference can return, and for solved items the
+    independently recomputed KKT residuals within eps_abs and equal to the reported norms; a random 64 of them (plus every item that did
+    NOT end solved, up to 8): status, counts and the oracle's bits."""
+    from qpdo_amd.problems import config_qp, kkt_residuals
+    count = 4096
+    probs = [config_qp("C3", i) for i in range(count)]
+    res, failed = solver.solve_batch(probs, verbose=0)
+    assert failed == 0 and len(res) == count
+    unsolved = []
+    for i, (p, r) in enumerate(zip(probs, res)):
+        gi = r["info"]
+        assert gi["status_val"] in (1, -3, -4, -5), (i, gi["status_val"])
+        if gi["status_val"] == 1:
+            rp, rd = kkt_residuals(p, r["x"], r["y"])
+            assert rp <= 1e-6 and rd <= 1e-6, (i, rp, rd)
+            assert abs(rp - gi["res_prim_norm"]) <= 1e-9 and abs(rd - gi["res_dual_norm"]) <= 1e-9, (i, rp, rd, gi)
+            assert gi["iterations"] < 10000
+        else:
+            unsolved.append(i)
+    assert len(unsolved) <= 40, len(unsolved)                 # (12 on this generator: instances that stall at res_prim ~ 1.2e-6, in the oracle too)
+    rng = np.random.default_rng(4096)
+    pick = sorted(set(rng.choice(count, 64, replace=False).tolist()) | set(unsolved[:8]))
+    bad = []
+    for i in pick:
+        o = ob.OracleSolver(probs[i], ob.default_settings())
+        ro = o.solve()
+        oi, ox, oy = dict(ro["info"]), np.array(ro["x"]), np.array(ro["y"])
+        o.close()
+        gi, r = res[i]["info"], res[i]
+        ok = (gi["status_val"], gi["iterations"], gi["oterations"]) == (oi["status_val"], oi["iterations"], oi["oterations"])
+        if ok and oi["status_val"] not in (-3, -4):
+            ok = np.array_equal(r["x"], ox) and np.array_equal(r["y"], oy) and gi["objective"] == oi["objective"] \
+                and gi["res_prim_norm"] == oi["res_prim_norm"] and gi["res_dual_norm"] == oi["res_dual_norm"]
+        if not ok:
+            bad.append((i, oi["status_val"], gi["status_val"], oi["iterations"], gi["iterations"]))
+    assert not bad, bad
