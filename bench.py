@@ -54,7 +54,7 @@ os.environ["QPDO_FIX_STATUS_RESET"] = "1"
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
 C3_COUNT = 4096           # BASELINE.json configs[2]
 MFMA_PROFILE = "r02_c2_dense_mfma_util_wide.json"   # (re-collected whenever k_ldl_syrk changes; unchanged since round 2)
-PMC_PROFILE = "r03_pmc_schur_inner_c4.json"     # HBM-traffic counters of the dominant kernel (tools/pmc_collect.sh writes it)
+PMC_PROFILE = "r04_pmc_schur_inner_c4.json"     # HBM-traffic counters of the dominant kernel (tools/profile_round.sh writes it)
 
 
 def parse():
@@ -606,6 +606,10 @@ def main():
             # HBM bytes per launch from the PMC counters cannot be collected inside this process: the figure is the average over
             # all real launches of this kernel in separate rocprofv3 --pmc passes over this same command (committed summary)
             pin = load_profile(PMC_PROFILE)
+            used_profile = PMC_PROFILE
+            if pin is None:                                      # (this round's collection not committed yet: the previous round's, under the same geometry check)
+                used_profile = PMC_PROFILE.replace("r04_", "r03_")
+                pin = load_profile(used_profile)
             ent = pin.get("k_spmv_slab<EpiSchurW>") if pin is not None else None
             live = ac_bytes / ac_n
             if ent is not None and ent.get("alg_bytes_per_launch_avg") and abs(ent["alg_bytes_per_launch_avg"] - live) <= 0.02 * live:
@@ -617,11 +621,11 @@ def main():
                 roof["traffic_age"] = pin.get("commit")
                 roof["traffic_source"] = ("profiles/%s (collected at commit %s): 2*FETCH_SIZE + WRITE_SIZE averaged over the %d real launches of this "
                                           "kernel in separate rocprofv3 --pmc passes over this command; its launch geometry (%.1f MB algorithmic per "
-                                          "launch) matches the live one (%.1f MB)" % (PMC_PROFILE, pin.get("commit"), ent["real_launches"],
+                                          "launch) matches the live one (%.1f MB)" % (used_profile, pin.get("commit"), ent["real_launches"],
                                                                                    ent["alg_bytes_per_launch_avg"] / 1e6, live / 1e6))
             else:
                 roof["traffic_source"] = ("none: profiles/%s is missing, or was collected on a build whose launches of this kernel moved a different "
-                                          "number of algorithmic bytes (stale) -- re-collect with tools/pmc_collect.sh" % PMC_PROFILE)
+                                          "number of algorithmic bytes (stale) -- re-collect with tools/profile_round.sh" % PMC_PROFILE)
         if at_n:
             q_t, q_b = s.bench_spmv(2, reps=5)
             roof["spmv_Q_live_GBs"] = q_b / (at_time / at_n) / 1e9

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Per-round profile collection on the GPU box (through gpurun, ~12 min):  usage: tools/profile_round.sh <round tag, e.g. r04> <commit>
+#  1. HBM traffic of the dominant kernel: two SEPARATE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with a trace
+#     domain) over the C4 bench command, reduced by tools/pmc_inner.py to <tag>_pmc_schur_inner_c4.json with the commit and the launch
+#     geometry of the same build.  The file is copied into profiles/ of THIS tree before step 3, so that the stored default bench line
+#     quotes counters of the build it ran on (round 3 ran the bench first and so always quoted the previous collection).
+#  2. rocprofv3 --kernel-trace --stats over the same command: per-kernel time of the C4 solve.
+#  3. the driver's default command (python3 bench.py), whole line with its extras.
+set -e
+TAG=${1:-r04}; COMMIT=${2:-unknown}
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+ARGS="bench.py --no-cpu-baseline --no-other-configs --no-mixed-extra"
+python3 $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+echo "plain run done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
+echo "fetch pass done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/bench_write.json 2> $OUT/bench_write.err
+echo "write pass done"
+F=$(find $OUT/fetch -name '*counter_collection.csv' | head -1)
+W=$(find $OUT/write -name '*counter_collection.csv' | head -1)
+python3 tools/pmc_inner.py "$F" "$W" $OUT/${TAG}_pmc_schur_inner_c4.json \
+  "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over $ARGS (C4 full solve, MI355X, round ${TAG#r})" "$COMMIT" $OUT/bench_plain.json > /dev/null
+rm -rf $OUT/fetch $OUT/write
+cp $OUT/${TAG}_pmc_schur_inner_c4.json profiles/${TAG}_pmc_schur_inner_c4.json
+echo "pmc done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o c4 -- python3 $ARGS > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+cp $(find $OUT/kt -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_c4_bench_kernel_stats.csv
+rm -rf $OUT/kt
+echo "kernel stats done"
+python3 bench.py > $OUT/${TAG}_c4_bench_default_run.json 2> $OUT/bench_default.err
+echo "bench done"
