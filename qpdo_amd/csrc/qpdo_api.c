@@ -442,8 +442,8 @@ QPDOWorkspace *qpdo_setup(const QPDOData *data, const QPDOSettings *settings) {
             if (prof) fprintf(stderr, "[setup] device create     %.3f s (upload of the CSC arrays, transpositions and slab tables on the device)\n", wall_now() - t0);
             const char *ls = getenv("QPDO_LINSOLVE");
             int mode = -1;
-            if (ls && !strcmp(ls, "pcg")) mode = 0; else if (ls && !strcmp(ls, "dense")) mode = 1;
-            qdev_configure(work->chol->dev, mode, env_double("QPDO_PCG_TOL", 0.0), env_int("QPDO_PCG_MAXIT", 0));
+            if (ls && !strcmp(ls, "pcg")) mode = 0; else if (ls && !strcmp(ls, "dense")) mode = 1; else if (ls && !strcmp(ls, "band")) mode = 3;
+            if (qdev_configure(work->chol->dev, mode, env_double("QPDO_PCG_TOL", 0.0), env_int("QPDO_PCG_MAXIT", 0))) { QPDO_EPRINT("device backend: %s", qdev_last_error()); goto fail; }
             on_device = 1;
         }
     }
@@ -514,8 +514,8 @@ QPDOWorkspace *qpdo_setup(const QPDOData *data, const QPDOSettings *settings) {
         if (rc) { QPDO_EPRINT("device backend: %s", qdev_last_error()); goto fail; }
         const char *ls = getenv("QPDO_LINSOLVE");
         int mode = -1;
-        if (ls && !strcmp(ls, "pcg")) mode = 0; else if (ls && !strcmp(ls, "dense")) mode = 1;
-        qdev_configure(work->chol->dev, mode, env_double("QPDO_PCG_TOL", 0.0), env_int("QPDO_PCG_MAXIT", 0));
+        if (ls && !strcmp(ls, "pcg")) mode = 0; else if (ls && !strcmp(ls, "dense")) mode = 1; else if (ls && !strcmp(ls, "band")) mode = 3;
+        if (qdev_configure(work->chol->dev, mode, env_double("QPDO_PCG_TOL", 0.0), env_int("QPDO_PCG_MAXIT", 0))) { QPDO_EPRINT("device backend: %s", qdev_last_error()); goto fail; }
     }
 
     if (settings->scaling) {

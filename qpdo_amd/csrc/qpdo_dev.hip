@@ -51,11 +51,13 @@ static int set_err(hipError_t e, const char *what, int line) {
 #include "dev/linesearch.inc"
 #include "dev/dense_kernels.inc"
 #include "dev/transpose.inc"
+#include "dev/band.inc"
 #include "dev/host_core.inc"
 
 extern "C" {
 #include "dev/host_setup.inc"
 #include "dev/host_pcg.inc"
 #include "dev/host_dense.inc"
+#include "dev/host_band.inc"
 #include "dev/host_step.inc"
 }  // extern "C"

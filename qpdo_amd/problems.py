@@ -84,6 +84,38 @@ def banded_qp(seed, n, n_rate=None, q_scale=1.0, box=1.0, rate=0.05, q_reg=0.0):
     return dict(n=n, m=m, Q=Q, Qstype=-1, A=A, q=q, l=l, u=u, c=0.0, seed=int(seed))
 
 
+def banded_random_qp(seed, n, bw, n_win=None, win=None):
+    """A random chain-structured QP with half-bandwidth `bw`: Q = symmetric band (random off-diagonals, diagonally dominant), constraints =
+    n box rows followed by n_win "window" rows with `win` consecutive random coefficients each (column span win - 1 <= bw): the pattern
+    of Q + A'DA has half-bandwidth exactly max(bw of Q, win - 1) for every D."""
+    rng = np.random.default_rng(seed)
+    win = min(bw + 1, 8) if win is None else int(win)
+    assert 1 <= win <= bw + 1
+    n_win = n // 2 if n_win is None else int(n_win)
+    diags, offs = [], []
+    tot = np.zeros(n)
+    for k in range(1, bw + 1):
+        if k > 3 and rng.random() < 0.5 and k != bw:
+            continue                                             # (a band with holes; the outermost diagonal is always there)
+        v = 0.3 * rng.standard_normal(n - k)
+        diags.append(v); offs.append(-k)
+        tot[:-k] += np.abs(v); tot[k:] += np.abs(v)
+    Q = sp.diags([tot + 0.05 + 0.1 * rng.random(n)] + diags, [0] + offs, format="csc")      # lower triangle
+    starts = np.sort(rng.integers(0, n - win + 1, n_win))
+    rows = np.concatenate([np.arange(n), n + np.repeat(np.arange(n_win), win)])
+    cols = np.concatenate([np.arange(n), (starts[:, None] + np.arange(win)[None, :]).ravel()])
+    vals = np.concatenate([np.ones(n), rng.standard_normal(n_win * win)])
+    m = n + n_win
+    A = sp.csc_matrix((vals, (rows, cols)), shape=(m, n))
+    A.sort_indices()
+    q = rng.standard_normal(n)
+    l = np.concatenate([-rng.random(n), -rng.random(n_win)])
+    u = np.concatenate([rng.random(n), rng.random(n_win)])
+    neq = n_win // 5
+    l[n:n + neq] = u[n:n + neq]                                      # some equality rows
+    return dict(n=n, m=m, Q=Q, Qstype=-1, A=A, q=q, l=l, u=u, c=0.0, seed=int(seed))
+
+
 def config_qp(name, index=0):
     cfg = CONFIGS[name]
     seed = BASE_SEED + 1000 * (list(CONFIGS).index(name) + 1) + index

