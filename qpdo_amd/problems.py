@@ -112,7 +112,7 @@ def banded_random_qp(seed, n, bw, n_win=None, win=None):
     l = np.concatenate([-rng.random(n), -rng.random(n_win)])
     u = np.concatenate([rng.random(n), rng.random(n_win)])
     neq = n_win // 5
-    l[n:n + neq] = u[n:n + neq]                                      # some equality rows
+    l[n:n + neq] = 0.0; u[n:n + neq] = 0.0                           # some equality rows (x = 0 stays feasible)
     return dict(n=n, m=m, Q=Q, Qstype=-1, A=A, q=q, l=l, u=u, c=0.0, seed=int(seed))
 
 
