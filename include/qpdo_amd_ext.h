@@ -7,7 +7,9 @@
  *
  * Environment variables read once per qpdo_setup:
  *   QPDO_DEVICE      HIP device ordinal (default: LOCAL_RANK if set, else 0)
- *   QPDO_LINSOLVE    "pcg" | "dense" | "auto" (default auto: dense LDL' for n <= QPDO_DENSE_MAX_N = 12288; the dense solver accepts
+ *   QPDO_LINSOLVE    "pcg" | "dense" | "band" | "auto" (default auto: the BAND direct solver when the Newton matrix is banded -- half-bandwidth
+ *                    of Q + A'A <= 127, chain-structured QPs -- and n >= 2048; otherwise dense LDL' for n <= QPDO_DENSE_MAX_N = 12288, PCG
+ *                    above; "band" on a matrix that is not banded makes qpdo_setup fail with a message; the dense solver accepts
  *                    n <= 40000 -- its assembly tiles the LDS accumulator, QPDO_DENSE_ASM_TILE rows at a time -- and is also the rescue of
  *                    a PCG solve that cannot converge up to that order)
  *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change, "1": low-rank update of the kept dense factor (default: from n = 2560 up)
@@ -61,7 +63,7 @@ typedef struct {
     long   spmv_calls;      /* SpMV launches in the last solve                             */
     double spmv_alg_bytes;  /* sum over those launches of 12 nnz + 4(rows+1) + 8 rows + 8 cols */
     long   factor_count;    /* dense LDL' factorizations                                   */
-    long   linsolve;        /* 0 pcg, 1 dense, 2 fused small-problem kernel                */
+    long   linsolve;        /* 0 pcg, 1 dense, 2 fused small-problem kernel, 3 band direct  */
     double spmv_Q_avg_s;    /* HIP-event average duration of the sampled Q SpMV inside PCG */
     long   spmv_Q_samples;
     double spmv_Ac_time_s;  /* Schur-mode inner solves: summed HIP-event time of the sampled A_c products ...          */
