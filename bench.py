@@ -777,6 +777,20 @@ def main():
             if not a.no_cpu_baseline:
                 c3["cpu_baseline"] = cpu_baseline_batch(probs[:256], 8.0, {})
             out["other_configs"]["C3_batch"] = c3
+            # one small QP through the drop-in API (qpdo_solve = one launch of the fused kernel): cold-solve latency
+            lat = {}
+            for name_, pq, stq_ in (("KAT_2x3", problems.infeasibility_kat("degenerate"), dict(max_iter=100)), ("C1b_n50_m100", problems.config_qp("C1b"), {}),
+                                    ("C3_size_n120_m360", problems.config_qp("C3", 0), {})):
+                sq = solver.QPDO().setup(pq["Q"], pq["q"], pq["A"], pq["l"], pq["u"], Qstype=-1, verbose=0, **stq_)
+                best = None
+                for _ in range(5):
+                    t0 = time.time(); rq = sq.solve(); dq = time.time() - t0
+                    best = dq if best is None or dq < best else best
+                stt_ = sq.stats()
+                lat[name_] = dict(cold_solve_ms=1e3 * best, kernel_ms=1e3 * stt_["fused_kernel_s"], passes=rq["info"]["iterations"], status_val=rq["info"]["status_val"],
+                                  route="fused one-launch kernel" if stt_["linsolve"] == 2 else "generic")
+                sq.delete()
+            out["other_configs"]["small_qp_latency"] = lat
         except Exception as e:
             out.setdefault("other_configs", {})["error"] = repr(e)
     if rank == 0:
