@@ -75,6 +75,7 @@ struct SmallRes {
     double *state_x, *state_Qx;              // modes 0, 2 out: final x and Qx into the workspace's vectors (qpdo_update_q reads them, qpdo.c:549-586); = st_x, st_Qx
     double *st_xbar, *st_Ax, *st_y, *st_ybar, *st_Aty, *st_mu, *st_isq;
     double ws_objective;
+    unsigned lds_vec_off;                    // byte offset inside the dynamic LDS of the item's vector workspace (nv, mv, iv), 0: it stays in global memory
     double *out_x, *out_y;                   // out: the internal (scaled) iterates, the host mirrors work->x / work->y (y after termination.c:85)
     QPDOAmdTraceRec *trace; long trace_cap, ntrace;      // optional per-pass trace (pinned host memory), records written / capacity
     double sigma_end, tau_end;
@@ -787,6 +788,14 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
             state_x = uni_ptr(Rg->state_x); state_Qx = uni_ptr(Rg->state_Qx); trace = uni_ptr(Rg->trace); trace_cap = Rg->trace_cap;
             out_x = uni_ptr(Rg->out_x); out_y = uni_ptr(Rg->out_y);
             mode = __builtin_amdgcn_readfirstlane(Rg->mode);
+            // One workspace has the CU to itself: its ~30 work vectors move from global memory (L2-resident, but every barrier that follows a
+            // vector update waits for the stores' round trip) into LDS when they fit beside the factor.  Same operations on the same values.
+            const unsigned voff = (unsigned)__builtin_amdgcn_readfirstlane((int)Rg->lds_vec_off);
+            if (voff) {
+                P.nv = uni_ptr((double *)((char *)dyn + voff));
+                P.mv = P.nv + (size_t)NV_COUNT * P.n;
+                P.iv = (int *)(P.mv + (size_t)MV_COUNT * P.m);
+            }
         }
     }
 #undef UNI_PTR
@@ -1533,6 +1542,7 @@ struct SmallResident {
     size_t lds = 0; int klds_ok = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t o_nv = 0, o_mv = 0, o_lsv = 0, o_iv = 0, o_tpos = 0, o_K = 0;
+    unsigned lds_vec_off = 0;
     double *h_x0 = nullptr, *h_y0 = nullptr;           // pinned copies of an explicit warm start's vectors (inside hout)
     long long *dprof = nullptr;                        // QPDO_SMALL_PROF=1: in-kernel phase ticks
 };
@@ -1577,6 +1587,13 @@ void *qdev_small_resident_create(const QdevSmallView *v, long trace_cap) {
     R->trace_cap = trace_cap;
     SHIP(hipEventCreate(&R->ev0)); SHIP(hipEventCreate(&R->ev1));
     R->lds = small_lds_bytes(n, m, &R->klds_ok);
+    {   // vectors into LDS when they fit beside everything else (QPDO_SMALL_VEC_LDS=0: keep them in global memory)
+        const size_t off = (R->lds + 15) & ~(size_t)15;
+        const size_t vbytes = ((size_t)NV_COUNT * n + (size_t)MV_COUNT * m) * 8 + 3 * m * 4 + 16;
+        const char *ve = getenv("QPDO_SMALL_VEC_LDS");
+        R->lds_vec_off = 0;
+        if (R->klds_ok && off + vbytes <= SMALL_LDS_BUDGET && !(ve && atoi(ve) == 0)) { R->lds_vec_off = (unsigned)off; R->lds = off + vbytes; }
+    }
     if (!R->klds_ok) { snprintf(s_err, sizeof(s_err), "resident fused solve: the packed factor of n = %d does not fit in LDS", v->n); rc = -1; goto done; }
     SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve_lat), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS_BUDGET));
 done:
@@ -1606,6 +1623,7 @@ static void resident_fill(SmallResident *R, const QdevSmallView *v, int mode, do
     r.st_y = v->st_y; r.st_ybar = v->st_ybar; r.st_Ax = v->st_Ax; r.st_mu = v->st_mu; r.st_isq = v->st_isq;
     r.out_x = h_x; r.out_y = h_y;
     r.trace = R->htrace; r.trace_cap = R->trace_cap;
+    r.lds_vec_off = R->lds_vec_off;
 }
 int qdev_small_resident_warm_start(void *h, const QdevSmallView *v, const void *settings_, const double *x_ws, const double *y_ws, double c_const,
                                    double *objective) {
