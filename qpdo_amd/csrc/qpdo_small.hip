@@ -848,8 +848,11 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
     // ---- warm start (qpdo.c:217-299) + initialize_mu (iteration.c:98-122) ----
     double sigma = st.sigma_init;
     if (LAT && mode == 2) {                         // the workspace's state, as qpdo_warm_start (mode 1) and any qpdo_update_* since left it
-        FOR_T(j, n) { x[j] = state_x[j]; xbar[j] = Rg->st_xbar[j]; Qx[j] = state_Qx[j]; Aty[j] = Rg->st_Aty[j]; }
-        FOR_T(i, m) { y[i] = Rg->st_y[i]; ybar[i] = Rg->st_ybar[i]; Ax[i] = Rg->st_Ax[i]; mu[i] = Rg->st_mu[i]; isq[i] = Rg->st_isq[i]; }
+        // (the descriptor lives in pinned host memory: its pointer fields are read ONCE, not per loop iteration)
+        const double *g_xbar = uni_ptr(Rg->st_xbar), *g_Aty = uni_ptr(Rg->st_Aty), *g_y = uni_ptr(Rg->st_y), *g_ybar = uni_ptr(Rg->st_ybar),
+                     *g_Ax = uni_ptr(Rg->st_Ax), *g_mu = uni_ptr(Rg->st_mu), *g_isq = uni_ptr(Rg->st_isq);
+        FOR_T(j, n) { x[j] = state_x[j]; xbar[j] = g_xbar[j]; Qx[j] = state_Qx[j]; Aty[j] = g_Aty[j]; }
+        FOR_T(i, m) { y[i] = g_y[i]; ybar[i] = g_ybar[i]; Ax[i] = g_Ax[i]; mu[i] = g_mu[i]; isq[i] = g_isq[i]; }
         SYNC;
     } else {
     if (P.x0) {
@@ -879,8 +882,10 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
     }
     }
     if (LAT && mode == 1) {                         // an explicit qpdo_warm_start: hand the state to the workspace and stop
-        FOR_T(j, n) { state_x[j] = x[j]; Rg->st_xbar[j] = xbar[j]; state_Qx[j] = Qx[j]; Rg->st_Aty[j] = Aty[j]; }
-        FOR_T(i, m) { Rg->st_y[i] = y[i]; Rg->st_ybar[i] = ybar[i]; Rg->st_Ax[i] = Ax[i]; Rg->st_mu[i] = mu[i]; Rg->st_isq[i] = isq[i]; }
+        double *g_xbar = uni_ptr(Rg->st_xbar), *g_Aty = uni_ptr(Rg->st_Aty), *g_y = uni_ptr(Rg->st_y), *g_ybar = uni_ptr(Rg->st_ybar),
+               *g_Ax = uni_ptr(Rg->st_Ax), *g_mu = uni_ptr(Rg->st_mu), *g_isq = uni_ptr(Rg->st_isq);
+        FOR_T(j, n) { state_x[j] = x[j]; g_xbar[j] = xbar[j]; state_Qx[j] = Qx[j]; g_Aty[j] = Aty[j]; }
+        FOR_T(i, m) { g_y[i] = y[i]; g_ybar[i] = ybar[i]; g_Ax[i] = Ax[i]; g_mu[i] = mu[i]; g_isq[i] = isq[i]; }
         if (threadIdx.x == 0) {
             double obj = small_objective(n, prox, sigma, Qx, x, P.q);     // qpdo.c:257 (compute_objective on the warm-started x)
             if (scaled) obj *= sc_cinv;

@@ -9,6 +9,7 @@ for name in ("C3", "C1"):
     s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0)
     s.solve()
     t = time.time(); r = s.solve(); cold = time.time() - t
+    cold_passes = r["info"]["iterations"]
     rng = np.random.default_rng(0)
     rows = []
     for k in range(12):
@@ -17,5 +18,5 @@ for name in ("C3", "C1"):
         rows.append((t1 - t0, t2 - t1, t3 - t2, r["info"]["iterations"], r["info"]["status_val"]))
     a = np.array(rows[2:])
     print("%s: cold solve %.2f ms (%d passes); re-solve medians: update_q %.3f ms, warm_start %.3f ms, solve %.3f ms, passes %s, status %s" % (
-        name, cold * 1e3, s.info()["iterations"], *(np.median(a[:, :3], axis=0) * 1e3), sorted(set(int(v) for v in a[:, 3])), sorted(set(int(v) for v in a[:, 4]))), flush=True)
+        name, cold * 1e3, cold_passes, *(np.median(a[:, :3], axis=0) * 1e3), sorted(set(int(v) for v in a[:, 3])), sorted(set(int(v) for v in a[:, 4]))), flush=True)
     s.delete()
