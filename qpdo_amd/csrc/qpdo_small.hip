@@ -203,6 +203,36 @@ __device__ void spmv_rows(int nrows, const int *rp, const int *ci, const double 
     }
 }
 
+// The same products with the LATENCY taken out: one thread per row walks its row as a chain of dependent loads (index -> x gather) from
+// L2-resident global memory -- ~36 hops for a row of A' at n = 120, m = 360: 5-6 us per product, four products per Newton pass.  Staged:
+// every thread forms val[k] * x[ci[k]] for a slice of ALL entries (one hop, fully parallel) into an LDS scratch (the union region, free at
+// every call site), then thread r adds row r's products from LDS in ascending k -- the multiplications and the additions of spmv_rows
+// in the same order, so the same bits.  Falls back to spmv_rows when the entries do not fit.  One extra barrier inside; the caller
+// synchronises before (x complete) and after (y complete) as for spmv_rows.
+__device__ void spmv_rows_staged(int nrows, const int *rp, const int *ci, const double *val, const double *x, double *y, double *scr, int cap) {
+    const int nnz = __builtin_amdgcn_readfirstlane(rp[nrows]);
+    if (nnz > cap) { spmv_rows(nrows, rp, ci, val, x, y); return; }
+    FOR_T(k, nnz) scr[k] = val[k] * x[ci[k]];
+    SYNC;
+    FOR_T(r, nrows) {
+        double s = 0.0;
+        for (int k = rp[r]; k < rp[r + 1]; k++) s += scr[k];
+        y[r] = s;
+    }
+}
+// two products of the same vector (Q x and A x) with one barrier between the phases
+__device__ void spmv2_rows_staged(int n1, const int *rp1, const int *ci1, const double *val1, double *y1, int n2, const int *rp2, const int *ci2,
+                                  const double *val2, double *y2, const double *x, double *scr, int cap) {
+    const int nnz1 = __builtin_amdgcn_readfirstlane(rp1[n1]), nnz2 = __builtin_amdgcn_readfirstlane(rp2[n2]);
+    if (nnz1 + nnz2 > cap) { spmv_rows(n1, rp1, ci1, val1, x, y1); spmv_rows(n2, rp2, ci2, val2, x, y2); return; }
+    double *s2 = scr + nnz1;
+    FOR_T(k, nnz1) scr[k] = val1[k] * x[ci1[k]];
+    FOR_T(k, nnz2) s2[k] = val2[k] * x[ci2[k]];
+    SYNC;
+    FOR_T(r, n1) { double s = 0.0; for (int k = rp1[r]; k < rp1[r + 1]; k++) s += scr[k]; y1[r] = s; }
+    FOR_T(r, n2) { double s = 0.0; for (int k = rp2[r]; k < rp2[r + 1]; k++) s += s2[k]; y2[r] = s; }
+}
+
 // ---- Ruiz + cost scaling (scaling.c:24-91) ----------------------------------------------------------
 __device__ void small_scale(SmallQP &P, int iters, double *D, double *Dinv, double *E, double *Einv, double *tn, double *tm,
                             double &c, double &cinv, double *sm) {
@@ -757,7 +787,8 @@ __device__ __forceinline__ T *uni_ptr(T *p) {
 // (qdev_small_resident_solve): the same code with the whole register file of a CU's SIMDs to itself (no spills) -- same operations
 // in the same order, so the same bits.
 template <int LAT>
-__device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, const QPDOSettings &st, int klds_ok) {
+__device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, const QPDOSettings &st, int kflags) {
+    const int klds_ok = kflags & 1, ucap = kflags >> 1;          // bit 0: the packed factor lives in LDS; the rest: doubles in the union region U
     __shared__ double sm[32];
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     // dynamic LDS: [xs: n][colbuf: n][tk: 2n][4n more for the four-column factorization][gbuf][d_s: m][rp_s: m+1][U], U = one region shared by the packed factor K
@@ -951,7 +982,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
                 if (st.eps_prim_inf > 0) {           // termination.c:97-151
                     FOR_T(i, m) dy[i] = y[i] - ybar[i];
                     SYNC;
-                    spmv_rows(n, P.Trp, P.Tci, P.Tval, dy, Atdy);
+                    spmv_rows_staged(n, P.Trp, P.Tci, P.Tval, dy, Atdy, Klds, ucap);
                     SYNC;
                     const double eps = st.eps_prim_inf * norm_inf(dy, scaled ? E : nullptr, m, sm);
                     if (eps != 0) {
@@ -983,8 +1014,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
                 if (st.eps_dual_inf > 0) {           // termination.c:156-216
                     FOR_T(j, n) dx[j] = x[j] - xbar[j];
                     SYNC;
-                    spmv_rows(n, P.Qrp, P.Qci, P.Qval, dx, Qdx);
-                    spmv_rows(m, P.Arp, P.Aci, P.Aval, dx, Adx);
+                    spmv2_rows_staged(n, P.Qrp, P.Qci, P.Qval, Qdx, m, rp_s, P.Aci, P.Aval, Adx, dx, Klds, ucap);
                     SYNC;
                     const double eps = st.eps_dual_inf * norm_inf(dx, scaled ? D : nullptr, n, sm);
                     if (eps != 0) {
@@ -1080,7 +1110,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
             else if (branch == 1) { if (ne + nl > 0) factor_valid = 0; }
             else if (!(last_branch == 2 && last_sigma_f == sigma_f)) factor_valid = 0;
             SYNC;
-            spmv_rows(n, P.Trp, P.Tci, P.Tval, dy, Atdy);
+            spmv_rows_staged(n, P.Trp, P.Tci, P.Tval, dy, Atdy, Klds, ucap);
             SYNC;
             FOR_T(j, n) rhs[j] = -res_dual_in[j] - Atdy[j];
             SYNC;
@@ -1115,13 +1145,12 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
             last_branch = branch; last_sigma_f = sigma_f;
             small_ldl_solve(P, kv, rhs, dx, xs);
             PH(PH_SOLVE);
-            spmv_rows(n, P.Qrp, P.Qci, P.Qval, dx, Qdx);
-            spmv_rows(m, P.Arp, P.Aci, P.Aval, dx, Adx);
+            spmv2_rows_staged(n, P.Qrp, P.Qci, P.Qval, Qdx, m, rp_s, P.Aci, P.Aval, Adx, dx, Klds, ucap);
             SYNC;
             if (prox) { FOR_T(j, n) Qdx[j] = Qdx[j] + sigma * dx[j]; }
             FOR_T(i, m) { if (active[i]) dy[i] += (Adx[i] / mu[i]); active_old[i] = active[i]; }
             SYNC;
-            spmv_rows(n, P.Trp, P.Tci, P.Tval, dy, Atdy);
+            spmv_rows_staged(n, P.Trp, P.Tci, P.Tval, dy, Atdy, Klds, ucap);
             SYNC;
             PH(PH_SPMV);
             if constexpr (LAT) tau = small_linesearch_impl(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf);
@@ -1294,7 +1323,7 @@ static int pinned_reserve(char **buf, size_t *cap, size_t need) {
 // else the linesearch scratch alone; the kernel's layout, k_small_solve).  klds_ok (optional out): 1 when K lives in LDS; passing
 // NULL sizes the K-in-global-memory layout.
 static const size_t SMALL_LDS_BUDGET = 160 * 1024 - 1024;                // static LDS: reduction scratch only
-static size_t small_lds_bytes(size_t nmax, size_t mmax, int *klds_ok) {
+static size_t small_lds_bytes(size_t nmax, size_t mmax, int *klds_ok, size_t *union_bytes = nullptr) {
     size_t lds = 8 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
     const size_t kbytes = nmax * (nmax + 1) / 2 * 8;
     size_t np2 = 1; while (np2 < 2 * mmax) np2 <<= 1;
@@ -1302,7 +1331,9 @@ static size_t small_lds_bytes(size_t nmax, size_t mmax, int *klds_ok) {
     { const size_t gdots = 8 * (2 * (mmax / 4 + 4) + 2 * (nmax / 4 + 4)); if (gdots > lsbytes) lsbytes = gdots; }   // the group arrays of the four dot products live there too
     const int ok = klds_ok && (lds + (kbytes > lsbytes ? kbytes : lsbytes) <= SMALL_LDS_BUDGET);
     if (klds_ok) *klds_ok = ok;
-    return lds + ((ok && kbytes > lsbytes) ? kbytes : lsbytes);
+    const size_t ub = (ok && kbytes > lsbytes) ? kbytes : lsbytes;
+    if (union_bytes) *union_bytes = ub;
+    return lds + ub;
 }
 static volatile double s_last_kernel_s = 0.0;   // (a statistic: written by whichever batch finished last; an aligned 8-byte store)
 //          // HIP-event duration of the last finished k_small_solve launch (bench.py's latency statement)
@@ -1402,13 +1433,14 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
         size_t nmax = 1, mmax = 0;
         for (long i = 0; i < count; i++) { if (items[i].data->n > nmax) nmax = items[i].data->n; if (items[i].data->m > mmax) mmax = items[i].data->m; }
         const size_t budget = SMALL_LDS_BUDGET;
-        int klds_ok = 0;
-        size_t lds = small_lds_bytes(nmax, mmax, &klds_ok);
-        if (const char *kg = getenv("QPDO_SMALL_K_GLOBAL")) { if (atoi(kg) && klds_ok) { klds_ok = 0; lds = small_lds_bytes(nmax, mmax, nullptr); } }      // occupancy experiments
+        int klds_ok = 0; size_t ubytes = 0;
+        size_t lds = small_lds_bytes(nmax, mmax, &klds_ok, &ubytes);
+        if (const char *kg = getenv("QPDO_SMALL_K_GLOBAL")) { if (atoi(kg) && klds_ok) { klds_ok = 0; lds = small_lds_bytes(nmax, mmax, nullptr, &ubytes); } }      // occupancy experiments
         SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(budget)));
         if (const char *pad = getenv("QPDO_SMALL_LDS_MIN")) { const size_t v = (size_t)atol(pad); if (v > lds && v <= budget) lds = v; }   // occupancy experiments
         SHIP(hipEventRecord(S.ev0, S.stream));
-        hipLaunchKernelGGL(k_small_solve, dim3((unsigned)count), dim3(SM_THREADS), lds, S.stream, S.dprobs, (int)count, *settings, klds_ok);
+        const int kflags = klds_ok | ((int)(ubytes / 8) << 1);       // (the LDS_MIN padding experiment below the launch only grows the tail)
+        hipLaunchKernelGGL(k_small_solve, dim3((unsigned)count), dim3(SM_THREADS), lds, S.stream, S.dprobs, (int)count, *settings, kflags);
         SHIP(hipEventRecord(S.ev1, S.stream));
     }
     SHIP(hipGetLastError());
@@ -1544,7 +1576,7 @@ struct SmallResident {
     struct HostBlock { SmallQP p; SmallRes r; } *hb = nullptr;      // pinned
     double *hout = nullptr;                            // pinned: sol_x(n) sol_y(m) x(n) y(m) dx(n) dy(m)
     QPDOAmdTraceRec *htrace = nullptr; long trace_cap = 0;           // pinned
-    size_t lds = 0; int klds_ok = 0;
+    size_t lds = 0; int klds_ok = 0, kflags = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t o_nv = 0, o_mv = 0, o_lsv = 0, o_iv = 0, o_tpos = 0, o_K = 0;
     unsigned lds_vec_off = 0;
@@ -1591,7 +1623,7 @@ void *qdev_small_resident_create(const QdevSmallView *v, long trace_cap) {
     SHIP(hipHostMalloc((void **)&R->htrace, (size_t)trace_cap * sizeof(QPDOAmdTraceRec), hipHostMallocDefault));
     R->trace_cap = trace_cap;
     SHIP(hipEventCreate(&R->ev0)); SHIP(hipEventCreate(&R->ev1));
-    R->lds = small_lds_bytes(n, m, &R->klds_ok);
+    { size_t ub = 0; R->lds = small_lds_bytes(n, m, &R->klds_ok, &ub); R->kflags = R->klds_ok | ((int)(ub / 8) << 1); }
     {   // vectors into LDS when they fit beside everything else (QPDO_SMALL_VEC_LDS=0: keep them in global memory)
         const size_t off = (R->lds + 15) & ~(size_t)15;
         const size_t vbytes = ((size_t)NV_COUNT * n + (size_t)MV_COUNT * m) * 8 + 3 * m * 4 + 16;
@@ -1640,7 +1672,7 @@ int qdev_small_resident_warm_start(void *h, const QdevSmallView *v, const void *
     resident_fill(R, v, 1, c_const);
     if (x_ws) { memcpy(R->h_x0, x_ws, n * 8); R->hb->p.x0 = R->h_x0; }         // pinned copies: the caller may release its vectors on return
     if (y_ws && m) { memcpy(R->h_y0, y_ws, m * 8); R->hb->p.y0 = R->h_y0; }
-    hipLaunchKernelGGL(k_small_solve_lat, dim3(1), dim3(SM_THREADS), R->lds, R->stream, &R->hb->p, 1, *settings, R->klds_ok);
+    hipLaunchKernelGGL(k_small_solve_lat, dim3(1), dim3(SM_THREADS), R->lds, R->stream, &R->hb->p, 1, *settings, R->kflags);
     SHIP(hipGetLastError());
     SHIP(hipStreamSynchronize(R->stream));
     *objective = R->hb->r.ws_objective;
@@ -1670,7 +1702,7 @@ int qdev_small_resident_solve(void *h, const QdevSmallView *v, const void *setti
     resident_fill(R, v, from_state ? 2 : 0, c_const);
     if (!prof) p.prof = nullptr;
     SHIP(hipEventRecord(R->ev0, R->stream));
-    hipLaunchKernelGGL(k_small_solve_lat, dim3(1), dim3(SM_THREADS), R->lds, R->stream, &R->hb->p, 1, *settings, R->klds_ok);
+    hipLaunchKernelGGL(k_small_solve_lat, dim3(1), dim3(SM_THREADS), R->lds, R->stream, &R->hb->p, 1, *settings, R->kflags);
     SHIP(hipGetLastError());
     SHIP(hipEventRecord(R->ev1, R->stream));
     SHIP(hipStreamSynchronize(R->stream));
