@@ -978,110 +978,113 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
         PH(PH_RESID);
         if (((iter > iter_old + 1) && inner_opt) || (iter == iter_old + st.inner_max_iter)) {
             if (tr) tr->kind = 1;
-            if (iter < iter_old + st.inner_max_iter) {
-                if (st.eps_prim_inf > 0) {           // termination.c:97-151
-                    FOR_T(i, m) dy[i] = y[i] - ybar[i];
-                    SYNC;
-                    spmv_rows_staged(n, P.Trp, P.Tci, P.Tval, dy, Atdy, Klds, ucap);
-                    SYNC;
-                    const double eps = st.eps_prim_inf * norm_inf(dy, scaled ? E : nullptr, m, sm);
-                    if (eps != 0) {
-                        if (scaled) { FOR_T(j, n) Atdy[j] = Dinv[j] * Atdy[j]; }
-                        SYNC;
-                        // the 2m terms in parallel into LDS (the union region is free between passes), then one lane adds
-                        // them in the reference's order: a serial loop over global memory cost ~0.2 ms per outer update
-                        FOR_T(i, m) {
-                            const double e = scaled ? E[i] : 1.0;
-                            ls_delta[2 * i] = (P.u[i] < e * SM_INFTY) ? P.u[i] * s_max(dy[i], 0) : 0;
-                            ls_delta[2 * i + 1] = (P.l[i] > -e * SM_INFTY) ? P.l[i] * s_min(dy[i], 0) : 0;
-                        }
-                        SYNC;
-                        if (threadIdx.x < 64) {
-                            const double oobs = wave0_fold(ls_delta, 2 * m, 0.0);
-                            if (threadIdx.x == 0) sm[18] = oobs;
-                        }
-                        SYNC;
-                        const double oob = sm[18];
-                        const double nat = norm_inf(Atdy, nullptr, n, sm);
-                        if ((nat <= eps) && (oob <= -eps)) {
-                            status = QPDO_PRIMAL_INFEASIBLE;
-                            if (scaled) { FOR_T(i, m) { double v = dy[i] * sc_cinv; dy[i] = E[i] * v; } }
-                            SYNC;
-                            break;
-                        }
+            // The outer update in a dozen barrier-separated phases instead of thirty (round 4): both infeasibility tests are evaluated
+            // TOGETHER and looked at once -- every quantity of termination.c:97-216 and iteration.c:127-180 with the operations and the
+            // summation orders of the step-by-step version (each test in its own block, each norm its own reduction), so the same bits:
+            // maxima are order free, the two sequential sums run side by side on two waves, and everything the dual test computes before
+            // the primal test has spoken goes to scratch (dxs) until the reference would have written it.
+            {
+                const bool chk = iter < iter_old + st.inner_max_iter;
+                const bool do_p = chk && st.eps_prim_inf > 0, do_d = chk && st.eps_dual_inf > 0;
+                const bool do_mu = (oter > 0) && (rpn > st.eps_abs);
+                double *dxs = tn;                                   // x - x_bar (the scaling's scratch vector is free after setup)
+                if (do_p) { FOR_T(i, m) dy[i] = y[i] - ybar[i]; }
+                if (do_d) { FOR_T(j, n) dxs[j] = x[j] - xbar[j]; }
+                SYNC;
+                double eps_p = 0.0, eps_d = 0.0, rn = 0.0;
+                {   // || E dy ||, || D dx ||, || res_prim || (update_mu's own norm, iteration.c:130) in one reduction
+                    double a = 0.0, bq = 0.0, c = 0.0, d4 = 0.0;
+                    if (do_p) { FOR_T(i, m) { const double v = s_abs(scaled ? dy[i] * E[i] : dy[i]); a = v > a ? v : a; } }
+                    if (do_d) { FOR_T(j, n) { const double v = s_abs(scaled ? dxs[j] * D[j] : dxs[j]); bq = v > bq ? v : bq; } }
+                    if (do_mu) { FOR_T(k, m) { const double v = s_abs(res_prim[k]); c = v > c ? v : c; } }
+                    blk_max4(a, bq, c, d4, sm);
+                    eps_p = st.eps_prim_inf * a; eps_d = st.eps_dual_inf * bq; rn = c;
+                }
+                const bool act_p = do_p && eps_p != 0, act_d = do_d && eps_d != 0;
+                if (act_p) { spmv_rows_staged(n, P.Trp, P.Tci, P.Tval, dy, Atdy, Klds, ucap); SYNC; }
+                if (act_d) { spmv2_rows_staged(n, P.Qrp, P.Qci, P.Qval, Qdx, m, rp_s, P.Aci, P.Aval, Adx, dxs, Klds, ucap); SYNC; }
+                double mx_at = 0.0, mx_q = 0.0, viol_f = 0.0;
+                if (act_p) {
+                    FOR_T(j, n) { double v = Atdy[j]; if (scaled) { v = Dinv[j] * v; Atdy[j] = v; } v = s_abs(v); mx_at = v > mx_at ? v : mx_at; }
+                    FOR_T(i, m) {                                   // the 2m bound terms, added in the reference's order below
+                        const double e = scaled ? E[i] : 1.0;
+                        ls_delta[2 * i] = (P.u[i] < e * SM_INFTY) ? P.u[i] * s_max(dy[i], 0) : 0;
+                        ls_delta[2 * i + 1] = (P.l[i] > -e * SM_INFTY) ? P.l[i] * s_min(dy[i], 0) : 0;
                     }
                 }
-                if (st.eps_dual_inf > 0) {           // termination.c:156-216
-                    FOR_T(j, n) dx[j] = x[j] - xbar[j];
+                const int ngq = n >> 2, cntq = ngq + (n - 4 * ngq);
+                if (act_d) {
+                    FOR_T(k, m) {
+                        double v = Adx[k]; const double e = scaled ? E[k] : 1.0;
+                        if (scaled) { v = Einv[k] * v; Adx[k] = v; }
+                        if ((P.u[k] < e * SM_INFTY && v >= eps_d) || (P.l[k] > -e * SM_INFTY && v <= -eps_d)) viol_f = 1.0;
+                    }
+                    FOR_T(j, n) { double qv = Qdx[j]; if (prox) qv = qv + (-sigma * tau) * dxs[j]; Qdx[j] = qv; qv = s_abs(qv); mx_q = qv > mx_q ? qv : mx_q; }
+                    // q'dx: the 4-groups of lin_alg.c:59-71 in parallel, added in order below
+                    FOR_T(g, ngq) { const int i = 4 * g; gbuf[g] = (P.q[i] * dxs[i] + P.q[i + 1] * dxs[i + 1] + P.q[i + 2] * dxs[i + 2] + P.q[i + 3] * dxs[i + 3]); }
+                    FOR_T(t, n - 4 * ngq) gbuf[ngq + t] = P.q[4 * ngq + t] * dxs[4 * ngq + t];
+                }
+                SYNC;
+                if (act_p && threadIdx.x < 64) { const double oobs = wave0_fold(ls_delta, 2 * m, 0.0); if (threadIdx.x == 0) sm[18] = oobs; }
+                if (act_d && threadIdx.x >= 64 && threadIdx.x < 128) { const double prod = wave0_fold(gbuf, cntq, 0.0); if (threadIdx.x == 64) sm[19] = prod; }
+                SYNC;
+                const double oob = sm[18], qdx = sm[19];
+                double nat = mx_at, nq = mx_q, viol_m = viol_f, d4 = 0.0;
+                blk_max4(nat, nq, viol_m, d4, sm);
+                if (act_p && (nat <= eps_p) && (oob <= -eps_p)) {
+                    status = QPDO_PRIMAL_INFEASIBLE;
+                    if (scaled) { FOR_T(i, m) { double v = dy[i] * sc_cinv; dy[i] = E[i] * v; } }
                     SYNC;
-                    spmv2_rows_staged(n, P.Qrp, P.Qci, P.Qval, Qdx, m, rp_s, P.Aci, P.Aval, Adx, dx, Klds, ucap);
-                    SYNC;
-                    const double eps = st.eps_dual_inf * norm_inf(dx, scaled ? D : nullptr, n, sm);
-                    if (eps != 0) {
-                        int viol = 0;
-                        FOR_T(k, m) {
-                            double v = Adx[k]; const double e = scaled ? E[k] : 1.0;
-                            if (scaled) { v = Einv[k] * v; Adx[k] = v; }
-                            if ((P.u[k] < e * SM_INFTY && v >= eps) || (P.l[k] > -e * SM_INFTY && v <= -eps)) viol = 1;
-                        }
-                        viol = blk_sum_int(viol, (int *)sm);
-                        if (!viol) {
-                            if (prox) { FOR_T(j, n) Qdx[j] = Qdx[j] + (-sigma * tau) * dx[j]; }
-                            SYNC;
-                            const double nq = norm_inf(Qdx, nullptr, n, sm);
-                            const double qdx = dot_seq(P.q, dx, n, sm, gbuf);
-                            const double cc = scaled ? sc_c : 1.0;
-                            if ((nq <= cc * eps) && (qdx <= -cc * eps)) {
-                                status = QPDO_DUAL_INFEASIBLE;
-                                if (scaled) { FOR_T(j, n) dx[j] = D[j] * dx[j]; }
-                                SYNC;
-                                break;
-                            }
-                        }
+                    break;
+                }
+                if (do_d) { FOR_T(j, n) dx[j] = dxs[j]; }            // (the reference's dx from here on: termination.c:166)
+                if (act_d && viol_m == 0.0) {
+                    const double cc = scaled ? sc_c : 1.0;
+                    if ((nq <= cc * eps_d) && (qdx <= -cc * eps_d)) {
+                        status = QPDO_DUAL_INFEASIBLE;
+                        SYNC;
+                        if (scaled) { FOR_T(j, n) dx[j] = D[j] * dx[j]; }
+                        SYNC;
+                        break;
                     }
                 }
-            }
-            FOR_T(j, n) xbar[j] = x[j];
-            FOR_T(i, m) ybar[i] = y[i];
-            SYNC;
-            if ((oter > 0) && (rpn > st.eps_abs)) {   // update_mu (iteration.c:127-168)
-                const double rn = norm_inf(res_prim, nullptr, m, sm);
+                // shift the estimates, update_mu (iteration.c:127-168), update_sigma (:173-180), keep res_prim: one elementwise phase
+                const double sigma_before = sigma;
+                const bool sig_upd = prox && (oter > 0) && (rdn > st.eps_abs) && (sigma > st.sigma_min);
+                if (sig_upd) sigma = s_max(sigma * st.sigma_upd, st.sigma_min);
+                FOR_T(j, n) { xbar[j] = x[j]; if (sig_upd) Qx[j] = Qx[j] + (sigma - sigma_before) * x[j]; }
                 int cnt = 0;
                 FOR_T(k, m) {
-                    int ch = 0;
-                    if (s_abs(res_prim[k]) > s_max(st.eps_abs, st.theta * s_abs(res_prim_old[k]))) {
-                        double mu_factor = 1.0 / s_min(1.0, st.delta * rn / s_abs(res_prim[k]));
-                        const double mu_new = mu[k] / mu_factor;
-                        if (mu_new >= st.mu_min) {
-                            if (mu[k] != mu_new) ch = 1;
-                            mu[k] = mu_new; mu_factor = sqrt(mu_factor); isq[k] = mu_factor * isq[k]; ats[k] = mu_factor;
-                        } else {
-                            if (mu[k] != st.mu_min) ch = 1;
-                            mu[k] = st.mu_min; ats[k] = isq_mu_min / isq[k]; isq[k] = isq_mu_min;
-                        }
-                    } else ats[k] = 1.0;
-                    changed[k] = ch; cnt += ch;
+                    ybar[k] = y[k];
+                    if (do_mu) {
+                        int ch = 0;
+                        if (s_abs(res_prim[k]) > s_max(st.eps_abs, st.theta * s_abs(res_prim_old[k]))) {
+                            double mu_factor = 1.0 / s_min(1.0, st.delta * rn / s_abs(res_prim[k]));
+                            const double mu_new = mu[k] / mu_factor;
+                            if (mu_new >= st.mu_min) {
+                                if (mu[k] != mu_new) ch = 1;
+                                mu[k] = mu_new; mu_factor = sqrt(mu_factor); isq[k] = mu_factor * isq[k]; ats[k] = mu_factor;
+                            } else {
+                                if (mu[k] != st.mu_min) ch = 1;
+                                mu[k] = st.mu_min; ats[k] = isq_mu_min / isq[k]; isq[k] = isq_mu_min;
+                            }
+                        } else ats[k] = 1.0;
+                        changed[k] = ch; cnt += ch;
+                    }
+                    res_prim_old[k] = res_prim[k];
                 }
-                cnt = blk_sum_int(cnt, (int *)sm);
-                if ((prox && sigma > st.sigma_min) || (cnt > 0.25 * SM_MAX_RANK_UPDATE)) reset_newton = 1;
-                else if (cnt > 0) {
-                    FOR_T(k, m) if (changed[k]) { const double s = sqrt(1 - 1 / (ats[k] * ats[k])); const double col = isq[k] * s; dw[k] += col * col; }
-                    factor_valid = 0;
-                    SYNC;
+                if (do_mu) {
+                    cnt = blk_sum_int(cnt, (int *)sm);
+                    if ((prox && sigma_before > st.sigma_min) || (cnt > 0.25 * SM_MAX_RANK_UPDATE)) reset_newton = 1;
+                    else if (cnt > 0) {
+                        FOR_T(k, m) if (changed[k]) { const double s = sqrt(1 - 1 / (ats[k] * ats[k])); const double col = isq[k] * s; dw[k] += col * col; }
+                        factor_valid = 0;
+                    }
                 }
+                if (sig_upd) reset_newton = 1;
+                SYNC;
+                if (chk) eps_in = s_max(st.rho * eps_in, 0.1 * st.eps_abs);
             }
-            if (prox && (oter > 0) && (rdn > st.eps_abs)) {   // update_sigma (iteration.c:173-180)
-                if (sigma > st.sigma_min) {
-                    const double old = sigma;
-                    sigma = s_max(sigma * st.sigma_upd, st.sigma_min);
-                    reset_newton = 1;
-                    FOR_T(j, n) Qx[j] = Qx[j] + (sigma - old) * x[j];
-                    SYNC;
-                }
-            }
-            if (iter < iter_old + st.inner_max_iter) eps_in = s_max(st.rho * eps_in, 0.1 * st.eps_abs);
-            FOR_T(i, m) res_prim_old[i] = res_prim[i];
-            SYNC;
             oter++; iter_old = iter;
             PH(PH_OUTER);
         } else {
