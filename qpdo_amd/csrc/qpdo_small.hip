@@ -98,9 +98,31 @@ __device__ __forceinline__ double s_mid(double a, double lo, double hi) { return
 // same bits -- executed by wave 0: its 64 lanes LOAD 64 elements at a time and the fold walks them with v_readlane (register to
 // register, ~16 cycles per element) instead of paying a dependent LDS round trip per element on one lane (measured on the batch
 // kernel's slowest items: 84 us -> 7 us for the 2m-element sums of a linesearch).  Call from all 64 lanes of wave 0.
+typedef __attribute__((address_space(3))) double lds_f64;      // a pointer KNOWN to address the workgroup's LDS: ds_read / ds_write, not flat
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
 __device__ __forceinline__ double rl64(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
+}
+// acc + v[0] + v[1] + ... in index order on one lane (or on every lane alike): the next eight elements are loaded while eight are added, so
+// an addition waits for the previous addition only -- ~10 cycles per element against ~30 for the readlane fold below and ~40 for a
+// loop that loads what it adds
+__device__ __forceinline__ double seq_fold(const lds_f64 *v, int count, double acc) {
+    int g = 0;
+    if (count >= 8) {
+        double a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7];
+#pragma nounroll
+        for (g = 8; g + 8 <= count; g += 8) {
+            const double b0 = v[g], b1 = v[g + 1], b2 = v[g + 2], b3 = v[g + 3], b4 = v[g + 4], b5 = v[g + 5], b6 = v[g + 6], b7 = v[g + 7];
+            acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+            a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
+        }
+        acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+    }
+    for (; g < count; g++) acc += v[g];
+    return acc;
 }
 __device__ __forceinline__ double wave0_fold(const double *v, int count, double acc) {
     const int lane = threadIdx.x & 63;
@@ -453,63 +475,58 @@ __device__ __forceinline__ void small_factor4_t(int n, double *__restrict__ K, d
 // x_j is broadcast with v_readlane, every row receives its subtractions in ascending (descending) j -- the operations of the column-
 // oriented loops below, element for element, so the same bits -- and the L entries of the next four steps are loaded before they are
 // needed (their addresses do not depend on x).  120 + 120 dependent steps of ~30 cycles instead of 120 workgroup barriers.
-template <int RPL>
-__device__ __forceinline__ void small_ldl_solve_wave(int n, const double *__restrict__ Kp, const double *__restrict__ b, double *__restrict__ xout) {
+// (round 4) The factor is addressed as LDS (ds_read; through the generic pointer every load was a flat_load inside its own exec-mask branch,
+// and the wave waited ~250 cycles for the four steps' entries before each group), every load is unconditional at a clamped address
+// (the guard sits on the update), and the entries of the NEXT group are in flight while a group is applied.
+template <int RPL, int GS>
+__device__ __forceinline__ void small_ldl_solve_wave(int n, const lds_f64 *__restrict__ Kp, const double *__restrict__ b, double *__restrict__ xout) {
     const int lane = threadIdx.x & 63;
-    double x[RPL]; int offi[RPL];
+    double x[RPL]; int offi[RPL], icl[RPL];
 #pragma unroll
-    for (int r = 0; r < RPL; r++) { const int i = lane + 64 * r; x[r] = i < n ? b[i] : 0.0; const int ic = i < n ? i : n - 1; offi[r] = ic * n - (ic * (ic + 1)) / 2; }
-    // L z = b: step j eliminates x_j from the rows below
+    for (int r = 0; r < RPL; r++) { const int i = lane + 64 * r; x[r] = i < n ? b[i] : 0.0; const int ic = i < n ? i : n - 1; icl[r] = ic; offi[r] = ic * n - (ic * (ic + 1)) / 2; }
+    double LA[GS][RPL], LB[GS][RPL];
+    // L z = b: step j eliminates x_j from the rows below;  L(i,j) sits at off(j) + i
+#define FWD_LOAD(L, j0_) do { _Pragma("unroll") for (int u = 0; u < GS; u++) { const int j = (j0_) + u; const int jc = j < n ? j : n - 1; const int offj = jc * n - (jc * (jc + 1)) / 2; \
+        _Pragma("unroll") for (int r = 0; r < RPL; r++) L[u][r] = Kp[offj + icl[r]]; } } while (0)
+#define FWD_STEPS(L, s_, jl_, j0_) do { _Pragma("unroll") for (int u = 0; u < GS; u++) { const int j = (j0_) + u; \
+        if (j < n - 1) { const double xj = rl64(x[s_], (jl_) + u); \
+            _Pragma("unroll") for (int r = 0; r < RPL; r++) { const int i = lane + 64 * r; if (i > j && i < n) x[r] = x[r] - L[u][r] * xj; } } } } while (0)
+    FWD_LOAD(LA, 0);
 #pragma unroll
     for (int s = 0; s < RPL; s++) {
-        for (int jl = 0; jl < 64; jl += 4) {
+        for (int jl = 0; jl < 64; jl += 2 * GS) {
             const int j0 = 64 * s + jl;
             if (j0 >= n - 1) break;
-            double Lv[4][RPL];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + u; const int jc = j < n ? j : n - 1; const int offj = jc * n - (jc * (jc + 1)) / 2;
-#pragma unroll
-                for (int r = 0; r < RPL; r++) { const int i = lane + 64 * r; Lv[u][r] = (j < n - 1 && i > j && i < n) ? Kp[offj + i] : 0.0; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + u;
-                if (j < n - 1) {
-                    const double xj = rl64(x[s], jl + u);
-#pragma unroll
-                    for (int r = 0; r < RPL; r++) { const int i = lane + 64 * r; if (i > j && i < n) x[r] = x[r] - Lv[u][r] * xj; }
-                }
-            }
+            FWD_LOAD(LB, j0 + GS);
+            FWD_STEPS(LA, s, jl, j0);
+            FWD_LOAD(LA, j0 + 2 * GS);
+            FWD_STEPS(LB, s, jl + GS, j0 + GS);
         }
     }
+#undef FWD_LOAD
+#undef FWD_STEPS
 #pragma unroll
-    for (int r = 0; r < RPL; r++) { const int i = lane + 64 * r; if (i < n) x[r] = x[r] / Kp[offi[r] + i]; }
+    for (int r = 0; r < RPL; r++) { const int i = lane + 64 * r; const double dg = Kp[offi[r] + icl[r]]; if (i < n) x[r] = x[r] / dg; }
     // L' x = z: step j (descending) eliminates x_j from the rows above;  L(j,i) sits at off(i) + j
+#define BWD_LOAD(L, j0_) do { _Pragma("unroll") for (int u = 0; u < GS; u++) { const int j = (j0_) - u; const int jc = j < 0 ? 0 : (j < n ? j : n - 1); \
+        _Pragma("unroll") for (int r = 0; r < RPL; r++) L[u][r] = Kp[offi[r] + jc]; } } while (0)
+#define BWD_STEPS(L, s_, jl_, j0_) do { _Pragma("unroll") for (int u = 0; u < GS; u++) { const int j = (j0_) - u; \
+        if (j >= 1 && j <= n - 1) { const double xj = rl64(x[s_], (jl_) - u); \
+            _Pragma("unroll") for (int r = 0; r < RPL; r++) { const int i = lane + 64 * r; if (i < j) x[r] = x[r] - L[u][r] * xj; } } } } while (0)
+    BWD_LOAD(LA, 64 * RPL - 1);
 #pragma unroll
     for (int s = RPL - 1; s >= 0; s--) {
-        for (int jl = 63; jl >= 0; jl -= 4) {
+        for (int jl = 63; jl >= 0; jl -= 2 * GS) {
             const int j0 = 64 * s + jl;
-            if (j0 - 3 > n - 1) continue;
             if (j0 < 1) break;
-            double Lv[4][RPL];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 - u;
-#pragma unroll
-                for (int r = 0; r < RPL; r++) { const int i = lane + 64 * r; Lv[u][r] = (j >= 1 && j <= n - 1 && i < j) ? Kp[offi[r] + j] : 0.0; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 - u;
-                if (j >= 1 && j <= n - 1) {
-                    const double xj = rl64(x[s], jl - u);
-#pragma unroll
-                    for (int r = 0; r < RPL; r++) { const int i = lane + 64 * r; if (i < j) x[r] = x[r] - Lv[u][r] * xj; }
-                }
-            }
+            BWD_LOAD(LB, j0 - GS);
+            if (j0 - (GS - 1) <= n - 1) BWD_STEPS(LA, s, jl, j0);
+            BWD_LOAD(LA, j0 - 2 * GS);
+            if (j0 - (2 * GS - 1) <= n - 1) BWD_STEPS(LB, s, jl - GS, j0 - GS);
         }
     }
+#undef BWD_LOAD
+#undef BWD_STEPS
 #pragma unroll
     for (int r = 0; r < RPL; r++) { const int i = lane + 64 * r; if (i < n) xout[i] = x[r]; }
 }
@@ -517,10 +534,11 @@ __device__ void small_ldl_solve(SmallQP &P, const KView &kv, const double *b, do
     const int n = P.n;
     if (kv.packed && n <= 256) {
         if (threadIdx.x < 64) {
-            if (n <= 64) small_ldl_solve_wave<1>(n, kv.K, b, xout);
-            else if (n <= 128) small_ldl_solve_wave<2>(n, kv.K, b, xout);
-            else if (n <= 192) small_ldl_solve_wave<3>(n, kv.K, b, xout);
-            else small_ldl_solve_wave<4>(n, kv.K, b, xout);
+            const lds_f64 *Kl = (const lds_f64 *)kv.K;             // packed => the factor is in the workgroup's LDS
+            if (n <= 64) small_ldl_solve_wave<1, 4>(n, Kl, b, xout);
+            else if (n <= 128) small_ldl_solve_wave<2, 4>(n, Kl, b, xout);
+            else if (n <= 192) small_ldl_solve_wave<3, 2>(n, Kl, b, xout);
+            else small_ldl_solve_wave<4, 2>(n, Kl, b, xout);
         }
         SYNC;
         return;
@@ -556,7 +574,7 @@ __device__ void small_ldl_solve(SmallQP &P, const KView &kv, const double *b, do
 // np2 = 1024.  The network and every comparison are those of the all-LDS version it replaces (one barrier per stage): the same
 // permutation, i.e. the stable order by (t, index) of the reference's qsort.  Ends with the sorted arrays in skey / sidx.
 template <int R>
-__device__ __forceinline__ void small_sort_regs(int np2, int M2, const double *ls_alpha, const double *ls_delta, u64 *skey, u32 *sidx) {
+__device__ __forceinline__ void small_sort_regs(int np2, int M2, const lds_f64 *ls_alpha, const lds_f64 *ls_delta, lds_u64 *skey, lds_u32 *sidx) {
     u64 key[R]; u32 idx[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -607,67 +625,119 @@ __device__ __forceinline__ void small_sort_regs(int np2, int M2, const double *l
 }
 // (its own function, not inlined: the kernel is held to 128 VGPRs, and inlined the register pressure of the sort and of the unrolled
 // folds below pushed spills into the factorization and solve loops -- measured: triangular solves 2x slower)
-__device__ __forceinline__ double small_linesearch_impl(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, unsigned char *jflag, double *tm, double *sm, u64 *skey, u32 *sidx, double *gbuf) {
-    const int n = P.n, m = P.m;
+__device__ __forceinline__ double small_linesearch_impl(SmallQP &P, double *V[], double *ls_delta_, double *ls_alpha_, unsigned char *jflag_, double *tm, double *sm_, u64 *skey_, u32 *sidx_, double *gbuf_, double *nscr_) {
+    const int n = P.n, m = P.m, M2 = 2 * m;
+    // every scratch array of the linesearch is in the workgroup's LDS; said so, the out-of-line copy of the batch kernel reads and writes
+    // them with ds instructions instead of flat ones (two counters to wait for, twice the latency)
+    lds_f64 *ls_delta = (lds_f64 *)ls_delta_, *ls_alpha = (lds_f64 *)ls_alpha_, *sm = (lds_f64 *)sm_, *gbuf = (lds_f64 *)gbuf_, *nscr = (lds_f64 *)nscr_;
+    lds_u8 *jflag = (lds_u8 *)jflag_; lds_u64 *skey = (lds_u64 *)skey_; lds_u32 *sidx = (lds_u32 *)sidx_;
     long long tls = P.prof ? wall_clock64() : 0;
 #define PHL(k) do { if (P.prof && threadIdx.x == 0) { const long long t_ = wall_clock64(); P.prof[k] += t_ - tls; tls = t_; } } while (0)
     double *dy = V[MV_DY], *mu = V[MV_MU], *isq = V[MV_ISQ], *w = V[MV_W], *y = V[MV_Y], *Adx = V[MV_ADX];
-    FOR_T(i, m) { double s = dy[i] * mu[i]; s = s * 0.5; tm[i] = s; }
-    // The four dot products of linesearch.c:19-25 together (round 3; were four dot_seq calls of three barriers each): all threads form
-    // the bracketed 4-groups of all four (lin_alg.c:59-71) into the union region, which nothing uses at this point, then lanes 0..3 of
-    // wave 0 each add the groups and the tail of ONE product in order -- four one-lane loops side by side in SIMD.
-    double eta, beta;
-    {
-        const double *dxv = P.nv + (size_t)NV_DX * n, *qdx = P.nv + (size_t)NV_QDX * n, *dfv = P.nv + (size_t)NV_DF * n;
-        const int ngm = m >> 2, cm = ngm + (m - 4 * ngm), ngn = n >> 2, cn = ngn + (n - 4 * ngn);
-        double *G0 = ls_delta, *G1 = G0 + cm, *G2 = G1 + cn, *G3 = G2 + cm;        // (2 cm + 2 cn doubles: the host sizes the union region for them)
-        SYNC;
-        FOR_T(g, ngm) { const int i = 4 * g;
-            G0[g] = (dy[i] * tm[i] + dy[i + 1] * tm[i + 1] + dy[i + 2] * tm[i + 2] + dy[i + 3] * tm[i + 3]);
-            G2[g] = (y[i] * tm[i] + y[i + 1] * tm[i + 1] + y[i + 2] * tm[i + 2] + y[i + 3] * tm[i + 3]); }
-        FOR_T(t, m - 4 * ngm) { G0[ngm + t] = dy[4 * ngm + t] * tm[4 * ngm + t]; G2[ngm + t] = y[4 * ngm + t] * tm[4 * ngm + t]; }
-        FOR_T(g, ngn) { const int i = 4 * g;
-            G1[g] = (dxv[i] * qdx[i] + dxv[i + 1] * qdx[i + 1] + dxv[i + 2] * qdx[i + 2] + dxv[i + 3] * qdx[i + 3]);
-            G3[g] = (dxv[i] * dfv[i] + dxv[i + 1] * dfv[i + 1] + dxv[i + 2] * dfv[i + 2] + dxv[i + 3] * dfv[i + 3]); }
-        FOR_T(t, n - 4 * ngn) { G1[ngn + t] = dxv[4 * ngn + t] * qdx[4 * ngn + t]; G3[ngn + t] = dxv[4 * ngn + t] * dfv[4 * ngn + t]; }
-        SYNC;
-        if (threadIdx.x < 4) {
-            const double *G = threadIdx.x == 0 ? G0 : threadIdx.x == 1 ? G1 : threadIdx.x == 2 ? G2 : G3;
-            const int cnt = (threadIdx.x & 1) ? cn : cm;
-            double prod = 0.0;
-            for (int g = 0; g < cnt; g++) prod += G[g];
-            sm[24 + threadIdx.x] = prod;
-        }
-        SYNC;
-        eta = sm[24]; eta += sm[25]; eta *= 0.5;
-        beta = sm[26]; beta += sm[27]; beta *= 0.5;
-        SYNC;                                        // the group arrays live where delta / alpha are written next
-    }
+    // Round 4: the whole linesearch of a pass that stops at its FIRST breakpoint -- 98.5 % of the passes of an instance that crawls towards
+    // eps for thousands of passes, 4 % of an ordinary solve's (counted on the C3 batch with an instrumented oracle) -- is two phases and
+    // two barriers; the sort (15-17 us of the former 34) runs only when the walk goes on.  linesearch.c:120-127 looks at the sorted
+    // breakpoints only through t[0] before the walk starts, and t[0] is the MINIMUM of the candidates: a minimum needs no order.
+    // Phase A, every thread: the bracketed 4-groups of the four dot products of linesearch.c:19-25 (lin_alg.c:59-71), delta / alpha
+    // (linesearch.c:27-40), the L / P / J flags of its two elements (linesearch.c:84-106) and the smallest positive t it has seen (the
+    // bits of a positive double order like an integer).  temp_m = 0.5 (dy .* mu) is recomputed where a group needs it: the same product,
+    // the same bits as the stored copy.  The group arrays live outside the union region (solve scratch, gbuf) and in the sort's key
+    // array, all idle here, so that delta / alpha can be written in the same phase.
+    const double *dxv = P.nv + (size_t)NV_DX * n, *qdx = P.nv + (size_t)NV_QDX * n, *dfv = P.nv + (size_t)NV_DF * n;
+    const int ngm = m >> 2, cm = ngm + (m - 4 * ngm), ngn = n >> 2, cn = ngn + (n - 4 * ngn);
+    lds_f64 *G0 = gbuf, *G1 = nscr, *G2 = (lds_f64 *)sidx, *G3 = nscr + cn;    // cm <= m/4 + 3 (gbuf; index array: >= m doubles), 2 cn <= n/2 + 6 <= 8n (nscr)
+    FOR_T(g, ngm) { const int i = 4 * g;
+        double t0 = dy[i] * mu[i], t1 = dy[i + 1] * mu[i + 1], t2 = dy[i + 2] * mu[i + 2], t3 = dy[i + 3] * mu[i + 3];
+        t0 = t0 * 0.5; t1 = t1 * 0.5; t2 = t2 * 0.5; t3 = t3 * 0.5;
+        G0[g] = (dy[i] * t0 + dy[i + 1] * t1 + dy[i + 2] * t2 + dy[i + 3] * t3);
+        G2[g] = (y[i] * t0 + y[i + 1] * t1 + y[i + 2] * t2 + y[i + 3] * t3); }
+    FOR_T(t, m - 4 * ngm) { const int i = 4 * ngm + t; double s = dy[i] * mu[i]; s = s * 0.5; G0[ngm + t] = dy[i] * s; G2[ngm + t] = y[i] * s; }
+    FOR_T(g, ngn) { const int i = 4 * g;
+        G1[g] = (dxv[i] * qdx[i] + dxv[i + 1] * qdx[i + 1] + dxv[i + 2] * qdx[i + 2] + dxv[i + 3] * qdx[i + 3]);
+        G3[g] = (dxv[i] * dfv[i] + dxv[i + 1] * dfv[i + 1] + dxv[i + 2] * dfv[i + 2] + dxv[i + 3] * dfv[i + 3]); }
+    FOR_T(t, n - 4 * ngn) { G1[ngn + t] = dxv[4 * ngn + t] * qdx[4 * ngn + t]; G3[ngn + t] = dxv[4 * ngn + t] * dfv[4 * ngn + t]; }
+    u64 kmin = ~0ull;
     FOR_T(i, m) {
-        double c0 = Adx[i] - tm[i]; c0 = c0 * isq[i];
-        ls_delta[i + m] = c0; ls_delta[i] = c0 * -1.0;
-        ls_alpha[i] = (w[i] - P.l[i]) * isq[i];
-        ls_alpha[i + m] = (P.u[i] - w[i]) * isq[i];
+        double s = dy[i] * mu[i]; s = s * 0.5; tm[i] = s;
+        double c0 = Adx[i] - s; c0 = c0 * isq[i];
+        const double d1 = c0, d0 = c0 * -1.0, a0 = (w[i] - P.l[i]) * isq[i], a1 = (P.u[i] - w[i]) * isq[i];
+        ls_delta[i + m] = d1; ls_delta[i] = d0; ls_alpha[i] = a0; ls_alpha[i + m] = a1;
+        const double q0 = a0 / d0, q1 = a1 / d1;
+        const int L0 = q0 > 0, L1 = q1 > 0, P0 = d0 > 0, P1 = d1 > 0;
+        jflag[i] = (unsigned char)(L0 | (((P0 + L0) == 1) << 1)); jflag[i + m] = (unsigned char)(L1 | (((P1 + L1) == 1) << 1));
+        if (L0) { const u64 k = (u64)__double_as_longlong(q0); kmin = k < kmin ? k : kmin; }
+        if (L1) { const u64 k = (u64)__double_as_longlong(q1); kmin = k < kmin ? k : kmin; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const u64 t = (u64)__shfl_down((long long)kmin, o, 64); kmin = t < kmin ? t : kmin; }
+    if ((threadIdx.x & 63) == 0) ((lds_u64 *)sm)[threadIdx.x >> 6] = kmin;         // sm[0 .. 7]
+    SYNC;
+    PHL(PH_LS_DOTS);
+    // Phase B, three waves side by side: lanes 0..3 of wave 0 each add the groups and the tail of ONE dot product in order; wave 1 the sum
+    // of delta^2 over J and the count of L, wave 2 the sum of delta*alpha over J (vec_prod_ind, linesearch.c:190-199: sequential, index
+    // order).  Only the elements IN J are added: each of the two waves first compacts its products, in index order (ballot + prefix
+    // count per 64-element chunk), into its half of the sort's key array, then adds them with the loads running ahead of the additions.
+    // J holds one element per active row -- a fifth of the 2m -- and never both elements of a row while l <= u; the former fold over all
+    // 2m (+0.0 for the others, 30 cycles per readlane step) took 9.5 us.
+    if (threadIdx.x < 4) {
+        const lds_f64 *G = threadIdx.x == 0 ? G0 : threadIdx.x == 1 ? G1 : threadIdx.x == 2 ? G2 : G3;
+        sm[24 + threadIdx.x] = seq_fold(G, (threadIdx.x & 1) ? cn : cm, 0.0);
+    } else if (threadIdx.x >= 64 && threadIdx.x < 192) {
+        const int lane = threadIdx.x & 63, second = (threadIdx.x >> 6) - 1;
+        lds_f64 *cb = (lds_f64 *)skey + (size_t)second * m;
+        double acc = 0.0; int nLc = 0, base = 0;
+        unsigned char f = lane < M2 ? jflag[lane] : 0;
+        double dl = lane < M2 ? ls_delta[lane] : 0.0, al = lane < M2 ? ls_alpha[lane] : 0.0;
+#pragma nounroll
+        for (int c = 0; c < M2; c += 64) {
+            const unsigned char fc = f;
+            const double v = second ? dl * al : dl * dl;
+            const int inx = c + 64 + lane;                                        // the next chunk is in flight while this one is placed
+            f = inx < M2 ? jflag[inx] : 0; dl = inx < M2 ? ls_delta[inx] : 0.0; al = inx < M2 ? ls_alpha[inx] : 0.0;
+            const bool inJ = (fc & 2) != 0;
+            const u64 mask = __ballot(inJ);
+            const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (inJ && pos < m) cb[pos] = v;
+            base += __popcll(mask);
+            if (!second) nLc += __popcll(__ballot(fc & 1));
+        }
+        if (base <= m) acc = seq_fold(cb, base, 0.0);
+        else {                                       // (bounds with l > u somewhere: more than m elements in J -- add them lane by lane)
+#pragma nounroll
+            for (int c = 0; c < M2; c += 64) {
+                const int i = c + lane;
+                const unsigned char fc = i < M2 ? jflag[i] : 0;
+                const double d_ = i < M2 ? ls_delta[i] : 0.0, a_ = i < M2 ? ls_alpha[i] : 0.0;
+                const double v = second ? d_ * a_ : d_ * d_;
+                u64 mask = __ballot((fc & 2) != 0);
+                while (mask) { const int l = __builtin_ctzll(mask); acc += rl64(v, l); mask &= mask - 1; }
+            }
+        }
+        if (lane == 0) { sm[28 + (second ? 0 : 1)] = acc; if (!second) sm[30] = (double)nLc; }      // sm[28]: delta*alpha, sm[29]: delta^2
     }
     SYNC;
-    // candidates: key = bits(t) for t > 0, sentinel otherwise; bitonic sort on (key, idx) == stable sort by t
-    const int M2 = 2 * m;
+    PHL(PH_LS_JSUM);
+    // every thread: eta, beta, a, b and the first breakpoint -- the same operations on the same values, so the same decision everywhere
+    double eta = sm[24]; eta += sm[25]; eta *= 0.5;
+    double beta = sm[26]; beta += sm[27]; beta *= 0.5;
+    const double sa = sm[29], sb = sm[28];
+    const int nL = (int)sm[30];
+    double a = eta + sa, b = beta - sb;
+    u64 k0 = ((lds_u64 *)sm)[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); i++) { const u64 t = ((lds_u64 *)sm)[i]; k0 = t < k0 ? t : k0; }
+    if (nL == 0 || b + a * __longlong_as_double((long long)k0) > 0) {               // linesearch.c:116-127
+        PHL(PH_LS_WALK);
+        return -b / a;                                 // (the caller's next barrier comes before anything writes sm or the scratch again)
+    }
+    // the walk goes on: stable order by (t, index) = the reference's qsort
     int np2 = 1; while (np2 < M2) np2 <<= 1;
-    PHL(PH_LS_DOTS);
     if (np2 <= SM_THREADS) small_sort_regs<1>(np2, M2, ls_alpha, ls_delta, skey, sidx);
     else if (np2 == 2 * SM_THREADS) small_sort_regs<2>(np2, M2, ls_alpha, ls_delta, skey, sidx);
     else small_sort_regs<4>(np2, M2, ls_alpha, ls_delta, skey, sidx);
     PHL(PH_LS_SORT);
-    // L / P / J flags in parallel; the J sums and the walk sequentially on one lane (linesearch.c:108-157).  The one-lane loops run at
-    // the latency of their dependent LDS reads unless the reads are taken out of the dependence chain: the J sums load groups of four
-    // elements before folding them (same additions, same order), and the walk reads (delta, alpha) from arrays that every thread
-    // has first rearranged INTO the sorted order (in place, through registers), so that it too can load ahead.
-    FOR_T(i, M2) {
-        const double dl = ls_delta[i], t = ls_alpha[i] / dl;
-        const int L = t > 0, Pp = dl > 0;
-        jflag[i] = (unsigned char)(L | (((Pp + L) == 1) << 1));
-    }
-    SYNC;
+    // The walk runs on one lane at the latency of its dependent LDS reads unless the reads are taken out of the dependence chain: it reads
+    // (delta, alpha) from arrays that every thread has first rearranged INTO the sorted order (in place, through registers), so that it
+    // can load ahead.
     const int per = (M2 + (int)blockDim.x - 1) / (int)blockDim.x;          // <= 4 sorted positions per thread (2m <= 2048)
     double gd[4], ga[4];
 #pragma unroll
@@ -676,24 +746,6 @@ __device__ __forceinline__ double small_linesearch_impl(SmallQP &P, double *V[],
         gd[r] = 0.0; ga[r] = 0.0;
         if (r < per && e < M2) { const u32 iz = sidx[e]; if (iz < (u32)M2) { gd[r] = ls_delta[iz]; ga[r] = ls_alpha[iz]; } }
     }
-    // J sums by wave 0: lane l takes element c + l; an element outside J contributes +0.0, which never changes a running sum that
-    // starts at +0.0 (x + 0 = x for x != -0, and such a sum is never -0: (+0) + (-0) = +0 and an exact cancellation gives +0)
-    double sa = 0.0, sb = 0.0; int nL = 0;
-    if (threadIdx.x < 128) {                       // wave 0: sum of delta^2 over J and the count of L; wave 1: sum of delta*alpha over J
-        const int lane = threadIdx.x & 63, second = threadIdx.x >> 6;
-#pragma nounroll
-        for (int c = 0; c < M2; c += 64) {
-            const int i = c + lane;
-            const unsigned char f = i < M2 ? jflag[i] : 0;
-            const double dl = i < M2 ? ls_delta[i] : 0.0, al = i < M2 ? ls_alpha[i] : 0.0;
-            const double v = (f & 2) ? (second ? dl * al : dl * dl) : 0.0;
-            if (!second) nL += __popcll(__ballot(f & 1));
-#pragma unroll
-            for (int l = 0; l < 64; l++) sa += rl64(v, l);
-        }
-        if (threadIdx.x == 64) sm[28] = sa;         // (wave 1's fold is the delta*alpha sum)
-    }
-    PHL(PH_LS_JSUM);
     SYNC;                                             // everyone is done with the index-ordered arrays
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -702,34 +754,26 @@ __device__ __forceinline__ double small_linesearch_impl(SmallQP &P, double *V[],
     }
     SYNC;
     if (threadIdx.x == 0) {
-        sb = sm[28];
-        double a = eta + sa, b = beta - sb, tau;
-        if (nL == 0) tau = -b / a;
-        else {
-            const double t0 = __longlong_as_double((long long)skey[0]);
-            if (b + a * t0 > 0) tau = -b / a;
-            else {
-                int i = 0; bool found = false;
+        double tau;
+        int i = 0; bool found = false;
 #pragma nounroll
-                while (i < nL - 1 && !found) {
-                    const int left = nL - 1 - i;
-                    double dl[4], al[4], tn[4];
+        while (i < nL - 1 && !found) {
+            const int left = nL - 1 - i;
+            double dl[4], al[4], tn[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) if (u < left) { dl[u] = ls_delta[i + u]; al[u] = ls_alpha[i + u]; tn[u] = __longlong_as_double((long long)skey[i + u + 1]); }
+            for (int u = 0; u < 4; u++) if (u < left) { dl[u] = ls_delta[i + u]; al[u] = ls_alpha[i + u]; tn[u] = __longlong_as_double((long long)skey[i + u + 1]); }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) if (u < left && !found) {
-                        if (dl[u] > 0) { a = a + dl[u] * dl[u]; b = b - dl[u] * al[u]; } else { a = a - dl[u] * dl[u]; b = b + dl[u] * al[u]; }
-                        i++;
-                        if (b + a * tn[u] > 0) found = true;
-                    }
-                }
-                if (!found) {
-                    const double dl = ls_delta[i], al = ls_alpha[i];
-                    if (dl > 0) { a = a + dl * dl; b = b - dl * al; } else { a = a - dl * dl; b = b + dl * al; }
-                }
-                tau = -b / a;
+            for (int u = 0; u < 4; u++) if (u < left && !found) {
+                if (dl[u] > 0) { a = a + dl[u] * dl[u]; b = b - dl[u] * al[u]; } else { a = a - dl[u] * dl[u]; b = b + dl[u] * al[u]; }
+                i++;
+                if (b + a * tn[u] > 0) found = true;
             }
         }
+        if (!found) {
+            const double dl = ls_delta[i], al = ls_alpha[i];
+            if (dl > 0) { a = a + dl * dl; b = b - dl * al; } else { a = a - dl * dl; b = b + dl * al; }
+        }
+        tau = -b / a;
         sm[17] = tau;
     }
     PHL(PH_LS_WALK);
@@ -738,8 +782,8 @@ __device__ __forceinline__ double small_linesearch_impl(SmallQP &P, double *V[],
     return sm[17];
 }
 // The batch kernel calls it out of line (see above); the latency variant, with twice the registers, inlines it (no pointer tables in scratch).
-__device__ __attribute__((noinline)) double small_linesearch(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, unsigned char *jflag, double *tm, double *sm, u64 *skey, u32 *sidx, double *gbuf) {
-    return small_linesearch_impl(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf);
+__device__ __attribute__((noinline)) double small_linesearch(SmallQP &P, double *V[], double *ls_delta, double *ls_alpha, unsigned char *jflag, double *tm, double *sm, u64 *skey, u32 *sidx, double *gbuf, double *nscr) {
+    return small_linesearch_impl(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf, nscr);
 }
 
 __device__ void small_status(QPDOInfo &info, long st) {
@@ -1156,8 +1200,8 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
             spmv_rows_staged(n, P.Trp, P.Tci, P.Tval, dy, Atdy, Klds, ucap);
             SYNC;
             PH(PH_SPMV);
-            if constexpr (LAT) tau = small_linesearch_impl(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf);
-            else tau = small_linesearch(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf);
+            if constexpr (LAT) tau = small_linesearch_impl(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf, dyn);
+            else tau = small_linesearch(P, V, ls_delta, ls_alpha, jflag, tm, sm, skey, sidx, gbuf, dyn);
             lds_has_factor = 0;                      // the scratch above lives in the factor's LDS region
             PH(PH_LS);
             FOR_T(j, n) { x[j] = x[j] + tau * dx[j]; Qx[j] = Qx[j] + tau * Qdx[j]; Aty[j] = Aty[j] + tau * Atdy[j]; }
