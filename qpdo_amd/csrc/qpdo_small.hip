@@ -188,6 +188,63 @@ __device__ void blk_sum_int3(int &a, int &b, int &c, int *sm) {
     for (int i = 0; i < nw; i++) { a += sm[i]; b += sm[8 + i]; c += sm[16 + i]; }
     SYNC;
 }
+// The same reductions with ONE barrier (round 4, the solve loop's): the partial results go to one of two banks of a scratch of their own,
+// taken in turn.  A wave can write bank(k+2) = bank(k) only after the barrier of reduction k+1, which every wave passes after it has
+// read bank(k) -- so neither the barrier before the partials are written nor the one after they are read is needed.  post / read can be
+// called apart (work that needs no result of the reduction, and other barriers, may come between them).
+struct RedBank { lds_f64 *red; int rb; };
+__device__ __forceinline__ lds_f64 *red_next(RedBank &B) { lds_f64 *R = B.red + 32 * B.rb; B.rb ^= 1; return R; }
+__device__ __forceinline__ void max4_post(double a, double b, double c, double d, lds_f64 *R) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double t = __shfl_down(a, o, 64); a = t > a ? t : a; t = __shfl_down(b, o, 64); b = t > b ? t : b;
+        t = __shfl_down(c, o, 64); c = t > c ? t : c; t = __shfl_down(d, o, 64); d = t > d ? t : d;
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { R[w] = a; R[8 + w] = b; R[16 + w] = c; R[24 + w] = d; }
+}
+__device__ __forceinline__ void max4_read(double &a, double &b, double &c, double &d, const lds_f64 *R) {
+    const int nw = blockDim.x >> 6;
+    a = R[0]; b = R[8]; c = R[16]; d = R[24];
+    for (int i = 1; i < nw; i++) { const double ta = R[i], tb = R[8 + i], tc = R[16 + i], td = R[24 + i]; a = ta > a ? ta : a; b = tb > b ? tb : b; c = tc > c ? tc : c; d = td > d ? td : d; }
+}
+__device__ __forceinline__ void blk_max4_1b(double &a, double &b, double &c, double &d, RedBank &B) {
+    lds_f64 *R = red_next(B);
+    max4_post(a, b, c, d, R);
+    SYNC;
+    max4_read(a, b, c, d, R);
+}
+__device__ __forceinline__ void blk_sum_int3_1b(int &a, int &b, int &c, RedBank &B) {
+    __attribute__((address_space(3))) int *R = (__attribute__((address_space(3))) int *)red_next(B);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); c += __shfl_down(c, o, 64); }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) { R[w] = a; R[8 + w] = b; R[16 + w] = c; }
+    SYNC;
+    a = 0; b = 0; c = 0;
+    for (int i = 0; i < nw; i++) { a += R[i]; b += R[8 + i]; c += R[16 + i]; }
+}
+// acc + the NONZERO elements of v[0 .. count) in index order, by one wave (call from all 64 lanes of it): an element that is +0.0 or
+// -0.0 never changes a running sum that starts at +0.0 (x + (+-0) = x, and such a sum is never -0), so leaving the zeros out gives the
+// bits of the sum over all.  The nonzero ones are first moved to the front of v, in order (ballot + prefix count per 64-element chunk;
+// a chunk is in registers before anything is written at or below it), then added by seq_fold.  v is destroyed.
+__device__ __forceinline__ double wave_fold_nonzero(lds_f64 *v, int count, double acc) {
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    double x = lane < count ? v[lane] : 0.0;
+#pragma nounroll
+    for (int c = 0; c < count; c += 64) {
+        const double xc = x;
+        const int inx = c + 64 + lane;
+        x = inx < count ? v[inx] : 0.0;
+        const bool nz = xc != 0.0;
+        const u64 mask = __ballot(nz);
+        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (nz) v[pos] = xc;
+        base += __popcll(mask);
+    }
+    return seq_fold(v, base, acc);
+}
 // inf-norm of a vector, or of a .* b when b != NULL (lin_alg.c:107-140: NaN never wins)
 __device__ double norm_inf(const double *a, const double *b, int n, double *sm) {
     double mx = 0.0;
@@ -834,6 +891,7 @@ template <int LAT>
 __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, const QPDOSettings &st, int kflags) {
     const int klds_ok = kflags & 1, ucap = kflags >> 1;          // bit 0: the packed factor lives in LDS; the rest: doubles in the union region U
     __shared__ double sm[32];
+    __shared__ double red_scr[64];                    // two banks of reduction partials (RedBank)
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     // dynamic LDS: [xs: n][colbuf: n][tk: 2n][4n more for the four-column factorization][gbuf][d_s: m][rp_s: m+1][U], U = one region shared by the packed factor K
     // (if it fits) and the linesearch scratch (delta, alpha, sort keys, sort indices, flags).  The linesearch of a
@@ -979,34 +1037,40 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
     double rpn = 0, rdn = 0, rpin = 0, rdin = 0;
     long long tph = P.prof ? wall_clock64() : 0;
     const long long t_solve = wall_clock64();
+    RedBank RB; RB.red = (lds_f64 *)red_scr; RB.rb = 0;
     const long long cyc0 = P.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
     for (iter = 0; iter < st.max_iter; iter++) {
-        // outer + inner residuals (iteration.c:30-93)
-        FOR_T(i, m) {
-            const double ax = Ax[i], yi = y[i];
-            double t;
-            if (scaled) { t = E[i] * yi; t = t * sc_cinv; t = E[i] * t; t = ax + t; } else t = ax + yi;
-            const double z = s_mid(t, P.l[i], P.u[i]);
-            res_prim[i] = ax - z;
-            const double wi = ax + mu[i] * (ybar[i] - 0.5 * yi);
-            w[i] = wi;
-            const double zin = s_mid(wi, P.l[i], P.u[i]);
-            res_prim_in[i] = ax + mu[i] * (ybar[i] - yi) - zin;
-        }
-        FOR_T(j, n) {
-            const double df0 = Qx[j] + P.q[j], aty = Aty[j];
-            double rd, dfi;
-            if (prox) { rd = df0 + (-sigma) * x[j]; rd = rd + aty; dfi = df0 + (-sigma) * xbar[j]; } else { rd = df0 + aty; dfi = df0; }
-            df[j] = dfi; res_dual[j] = rd; res_dual_in[j] = dfi + aty;
-        }
-        SYNC;
-        {   // the four residual norms with one pair of barriers (were four reductions)
+        // outer + inner residuals (iteration.c:30-93) and their four norms: every thread takes the maxima over the entries it has just
+        // formed, one reduction with one barrier follows (round 4; was: residuals, barrier, a second pass over them, three more barriers)
+        {
             double m1 = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0;
-            FOR_T(i, m) { const double e = scaled ? Einv[i] : 1.0; const double a1 = s_abs(scaled ? res_prim[i] * e : res_prim[i]), a3 = s_abs(scaled ? res_prim_in[i] * e : res_prim_in[i]);
-                          m1 = a1 > m1 ? a1 : m1; m3 = a3 > m3 ? a3 : m3; }
-            FOR_T(j, n) { const double e = scaled ? Dinv[j] : 1.0; const double a2 = s_abs(scaled ? res_dual[j] * e : res_dual[j]), a4 = s_abs(scaled ? res_dual_in[j] * e : res_dual_in[j]);
-                          m2 = a2 > m2 ? a2 : m2; m4 = a4 > m4 ? a4 : m4; }
-            blk_max4(m1, m2, m3, m4, sm);
+            FOR_T(i, m) {
+                const double ax = Ax[i], yi = y[i];
+                double t;
+                if (scaled) { t = E[i] * yi; t = t * sc_cinv; t = E[i] * t; t = ax + t; } else t = ax + yi;
+                const double z = s_mid(t, P.l[i], P.u[i]);
+                const double rp = ax - z;
+                res_prim[i] = rp;
+                const double wi = ax + mu[i] * (ybar[i] - 0.5 * yi);
+                w[i] = wi;
+                const double zin = s_mid(wi, P.l[i], P.u[i]);
+                const double rpi = ax + mu[i] * (ybar[i] - yi) - zin;
+                res_prim_in[i] = rpi;
+                const double e = scaled ? Einv[i] : 1.0;
+                const double a1 = s_abs(scaled ? rp * e : rp), a3 = s_abs(scaled ? rpi * e : rpi);
+                m1 = a1 > m1 ? a1 : m1; m3 = a3 > m3 ? a3 : m3;
+            }
+            FOR_T(j, n) {
+                const double df0 = Qx[j] + P.q[j], aty = Aty[j];
+                double rd, dfi;
+                if (prox) { rd = df0 + (-sigma) * x[j]; rd = rd + aty; dfi = df0 + (-sigma) * xbar[j]; } else { rd = df0 + aty; dfi = df0; }
+                const double rdi = dfi + aty;
+                df[j] = dfi; res_dual[j] = rd; res_dual_in[j] = rdi;
+                const double e = scaled ? Dinv[j] : 1.0;
+                const double a2 = s_abs(scaled ? rd * e : rd), a4 = s_abs(scaled ? rdi * e : rdi);
+                m2 = a2 > m2 ? a2 : m2; m4 = a4 > m4 ? a4 : m4;
+            }
+            blk_max4_1b(m1, m2, m3, m4, RB);
             rpn = m1; rdn = m2; rpin = m3; rdin = m4;
             if (scaled) { rdn *= sc_cinv; rdin *= sc_cinv; }
         }
@@ -1032,21 +1096,35 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
                 const bool do_p = chk && st.eps_prim_inf > 0, do_d = chk && st.eps_dual_inf > 0;
                 const bool do_mu = (oter > 0) && (rpn > st.eps_abs);
                 double *dxs = tn;                                   // x - x_bar (the scaling's scratch vector is free after setup)
-                if (do_p) { FOR_T(i, m) dy[i] = y[i] - ybar[i]; }
-                if (do_d) { FOR_T(j, n) dxs[j] = x[j] - xbar[j]; }
-                SYNC;
                 double eps_p = 0.0, eps_d = 0.0, rn = 0.0;
-                {   // || E dy ||, || D dx ||, || res_prim || (update_mu's own norm, iteration.c:130) in one reduction
+                {   // dy = y - y_bar, dx = x - x_bar with || E dy ||, || D dx || taken as they are formed, and || res_prim || (update_mu's own
+                    // norm, iteration.c:130): one reduction, one barrier
                     double a = 0.0, bq = 0.0, c = 0.0, d4 = 0.0;
-                    if (do_p) { FOR_T(i, m) { const double v = s_abs(scaled ? dy[i] * E[i] : dy[i]); a = v > a ? v : a; } }
-                    if (do_d) { FOR_T(j, n) { const double v = s_abs(scaled ? dxs[j] * D[j] : dxs[j]); bq = v > bq ? v : bq; } }
+                    if (do_p) { FOR_T(i, m) { const double dv = y[i] - ybar[i]; dy[i] = dv; const double v = s_abs(scaled ? dv * E[i] : dv); a = v > a ? v : a; } }
+                    if (do_d) { FOR_T(j, n) { const double dv = x[j] - xbar[j]; dxs[j] = dv; const double v = s_abs(scaled ? dv * D[j] : dv); bq = v > bq ? v : bq; } }
                     if (do_mu) { FOR_T(k, m) { const double v = s_abs(res_prim[k]); c = v > c ? v : c; } }
-                    blk_max4(a, bq, c, d4, sm);
+                    blk_max4_1b(a, bq, c, d4, RB);
                     eps_p = st.eps_prim_inf * a; eps_d = st.eps_dual_inf * bq; rn = c;
                 }
                 const bool act_p = do_p && eps_p != 0, act_d = do_d && eps_d != 0;
-                if (act_p) { spmv_rows_staged(n, P.Trp, P.Tci, P.Tval, dy, Atdy, Klds, ucap); SYNC; }
-                if (act_d) { spmv2_rows_staged(n, P.Qrp, P.Qci, P.Qval, Qdx, m, rp_s, P.Aci, P.Aval, Adx, dxs, Klds, ucap); SYNC; }
+                // A' dy, Q dx, A dx: the products of all three staged in ONE phase when the union region holds them (spmv_rows_staged)
+                {
+                    const int nzT = __builtin_amdgcn_readfirstlane(P.Trp[n]), nzQ = __builtin_amdgcn_readfirstlane(P.Qrp[n]), nzA = __builtin_amdgcn_readfirstlane(rp_s[m]);
+                    if (act_p && act_d && nzT + nzQ + nzA <= ucap) {
+                        double *s1 = Klds, *s2 = s1 + nzT, *s3 = s2 + nzQ;
+                        FOR_T(k, nzT) s1[k] = P.Tval[k] * dy[P.Tci[k]];
+                        FOR_T(k, nzQ) s2[k] = P.Qval[k] * dxs[P.Qci[k]];
+                        FOR_T(k, nzA) s3[k] = P.Aval[k] * dxs[P.Aci[k]];
+                        SYNC;
+                        FOR_T(r, n) { double sacc = 0.0; for (int k = P.Trp[r]; k < P.Trp[r + 1]; k++) sacc += s1[k]; Atdy[r] = sacc; }
+                        FOR_T(r, n) { double sacc = 0.0; for (int k = P.Qrp[r]; k < P.Qrp[r + 1]; k++) sacc += s2[k]; Qdx[r] = sacc; }
+                        FOR_T(r, m) { double sacc = 0.0; for (int k = rp_s[r]; k < rp_s[r + 1]; k++) sacc += s3[k]; Adx[r] = sacc; }
+                        SYNC;                                     // (the staged products sit where the bound terms are written next)
+                    } else {
+                        if (act_p) { spmv_rows_staged(n, P.Trp, P.Tci, P.Tval, dy, Atdy, Klds, ucap); SYNC; }
+                        if (act_d) { spmv2_rows_staged(n, P.Qrp, P.Qci, P.Qval, Qdx, m, rp_s, P.Aci, P.Aval, Adx, dxs, Klds, ucap); SYNC; }
+                    }
+                }
                 double mx_at = 0.0, mx_q = 0.0, viol_f = 0.0;
                 if (act_p) {
                     FOR_T(j, n) { double v = Atdy[j]; if (scaled) { v = Dinv[j] * v; Atdy[j] = v; } v = s_abs(v); mx_at = v > mx_at ? v : mx_at; }
@@ -1068,13 +1146,18 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
                     FOR_T(g, ngq) { const int i = 4 * g; gbuf[g] = (P.q[i] * dxs[i] + P.q[i + 1] * dxs[i + 1] + P.q[i + 2] * dxs[i + 2] + P.q[i + 3] * dxs[i + 3]); }
                     FOR_T(t, n - 4 * ngq) gbuf[ngq + t] = P.q[4 * ngq + t] * dxs[4 * ngq + t];
                 }
+                // the three maxima of this phase are posted before the barrier that publishes the bound terms and read after the one that
+                // publishes the two sequential sums: the sum of the bound terms on wave 0 -- only the NONZERO ones, at most one per row with
+                // dy != 0, moved to the front in order (wave_fold_nonzero; the fold over all 2m took 9 us) -- and q'dx on wave 1
+                lds_f64 *Rm = red_next(RB);
+                max4_post(mx_at, mx_q, viol_f, 0.0, Rm);
                 SYNC;
-                if (act_p && threadIdx.x < 64) { const double oobs = wave0_fold(ls_delta, 2 * m, 0.0); if (threadIdx.x == 0) sm[18] = oobs; }
-                if (act_d && threadIdx.x >= 64 && threadIdx.x < 128) { const double prod = wave0_fold(gbuf, cntq, 0.0); if (threadIdx.x == 64) sm[19] = prod; }
+                if (act_p && threadIdx.x < 64) { const double oobs = wave_fold_nonzero((lds_f64 *)ls_delta, 2 * m, 0.0); if (threadIdx.x == 0) sm[18] = oobs; }
+                if (act_d && threadIdx.x >= 64 && threadIdx.x < 128) { const double prod = seq_fold((const lds_f64 *)gbuf, cntq, 0.0); if (threadIdx.x == 64) sm[19] = prod; }
                 SYNC;
                 const double oob = sm[18], qdx = sm[19];
-                double nat = mx_at, nq = mx_q, viol_m = viol_f, d4 = 0.0;
-                blk_max4(nat, nq, viol_m, d4, sm);
+                double nat, nq, viol_m, d4;
+                max4_read(nat, nq, viol_m, d4, Rm);
                 if (act_p && (nat <= eps_p) && (oob <= -eps_p)) {
                     status = QPDO_PRIMAL_INFEASIBLE;
                     if (scaled) { FOR_T(i, m) { double v = dy[i] * sc_cinv; dy[i] = E[i] * v; } }
@@ -1118,7 +1201,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
                     res_prim_old[k] = res_prim[k];
                 }
                 if (do_mu) {
-                    cnt = blk_sum_int(cnt, (int *)sm);
+                    { int c2 = 0, c3 = 0; blk_sum_int3_1b(cnt, c2, c3, RB); }
                     if ((prox && sigma_before > st.sigma_min) || (cnt > 0.25 * SM_MAX_RANK_UPDATE)) reset_newton = 1;
                     else if (cnt > 0) {
                         FOR_T(k, m) if (changed[k]) { const double s = sqrt(1 - 1 / (ats[k] * ats[k])); const double col = isq[k] * s; dw[k] += col * col; }
@@ -1139,7 +1222,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
                 const int act = (w[i] <= P.l[i]) || (w[i] >= P.u[i]);
                 active[i] = act; na += act; ne += (act && !active_old[i]); nl += (!act && active_old[i]);
             }
-            blk_sum_int3(na, ne, nl, (int *)sm);
+            blk_sum_int3_1b(na, ne, nl, RB);
             int branch;
             if ((reset_newton && na) || (ne + nl) > SM_MAX_RANK_UPDATE) { reset_newton = 0; branch = 0; }
             else if (na) branch = 1; else branch = 2;
@@ -1158,8 +1241,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
             else if (!(last_branch == 2 && last_sigma_f == sigma_f)) factor_valid = 0;
             SYNC;
             spmv_rows_staged(n, P.Trp, P.Tci, P.Tval, dy, Atdy, Klds, ucap);
-            SYNC;
-            FOR_T(j, n) rhs[j] = -res_dual_in[j] - Atdy[j];
+            FOR_T(j, n) rhs[j] = -res_dual_in[j] - Atdy[j];      // (entry j of the product was written by this very thread: no barrier between)
             SYNC;
             PH(PH_PREP);
             // The factor is a function of (sigma_f, d) alone.  The reference refactors whenever reset_newton is set -- after EVERY outer
@@ -1170,7 +1252,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
             if (!factor_valid && have_fact && sigma_f == fact_sigma_f) {
                 int diff = 0;
                 FOR_T(i, m) diff |= (__double_as_longlong(dw[i]) != __double_as_longlong(dwf[i]));
-                diff = blk_sum_int(diff, (int *)sm);
+                { int c2 = 0, c3 = 0; blk_sum_int3_1b(diff, c2, c3, RB); }
                 if (!diff) factor_valid = 1;
             }
             if (!factor_valid) {
@@ -1193,8 +1275,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
             small_ldl_solve(P, kv, rhs, dx, xs);
             PH(PH_SOLVE);
             spmv2_rows_staged(n, P.Qrp, P.Qci, P.Qval, Qdx, m, rp_s, P.Aci, P.Aval, Adx, dx, Klds, ucap);
-            SYNC;
-            if (prox) { FOR_T(j, n) Qdx[j] = Qdx[j] + sigma * dx[j]; }
+            if (prox) { FOR_T(j, n) Qdx[j] = Qdx[j] + sigma * dx[j]; }      // (own entries of both products: no barrier between)
             FOR_T(i, m) { if (active[i]) dy[i] += (Adx[i] / mu[i]); active_old[i] = active[i]; }
             SYNC;
             spmv_rows_staged(n, P.Trp, P.Tci, P.Tval, dy, Atdy, Klds, ucap);

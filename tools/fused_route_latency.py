@@ -9,7 +9,8 @@ for a in sys.argv[1:]:
     extra[k] = float(v) if "." in v or "e" in v else int(v)
 cases = [("C3#0", problems.config_qp("C3", 0), {}), ("C1b", problems.config_qp("C1b"), dict(max_iter=200)),
          ("KAT", problems.infeasibility_kat("degenerate"), dict(max_iter=100)), ("n60m180", problems.random_qp(9, 60, 180, 0.1, 20), {}),
-         ("n150m400", problems.random_qp(8, 150, 400, 0.05, 50), {})]
+         ("n150m400", problems.random_qp(8, 150, 400, 0.05, 50), {}),
+         ("C3#322 (never reaches eps: 10000 passes)", problems.config_qp("C3", 322), {})]
 for name, p, st in cases:
     st = dict(st, **extra)
     s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0, **st)
