@@ -106,10 +106,12 @@ __device__ __forceinline__ double rl64(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
-// acc + v[0] + v[1] + ... in index order on one lane (or on every lane alike): the next eight elements are loaded while eight are added, so
-// an addition waits for the previous addition only -- ~10 cycles per element against ~30 for the readlane fold below and ~40 for a
-// loop that loads what it adds
-__device__ __forceinline__ double seq_fold(const lds_f64 *v, int count, double acc) {
+// (+0.0) + v[0] + v[1] + ... in index order on one lane (or on every lane alike; lanes may differ in v and count): the next eight
+// elements are loaded while eight are added, so an addition waits for the previous addition only -- ~10 cycles per element against ~30
+// for the readlane fold below and ~100 for a loop that loads what it adds.  The last count % 8 elements are loaded together and padded
+// with +0.0, which never changes a sum that started at +0.0 (such a sum is never -0).
+__device__ __forceinline__ double seq_fold(const lds_f64 *v, int count) {
+    double acc = 0.0;
     int g = 0;
     if (count >= 8) {
         double a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7];
@@ -121,7 +123,14 @@ __device__ __forceinline__ double seq_fold(const lds_f64 *v, int count, double a
         }
         acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
     }
-    for (; g < count; g++) acc += v[g];
+    const int rem = count - g;
+    if (rem > 0) {
+        double t[7];
+#pragma unroll
+        for (int u = 0; u < 7; u++) t[u] = v[g + (u < rem ? u : 0)];
+#pragma unroll
+        for (int u = 0; u < 7; u++) acc += (u < rem ? t[u] : 0.0);
+    }
     return acc;
 }
 __device__ __forceinline__ double wave0_fold(const double *v, int count, double acc) {
@@ -224,11 +233,11 @@ __device__ __forceinline__ void blk_sum_int3_1b(int &a, int &b, int &c, RedBank 
     a = 0; b = 0; c = 0;
     for (int i = 0; i < nw; i++) { a += R[i]; b += R[8 + i]; c += R[16 + i]; }
 }
-// acc + the NONZERO elements of v[0 .. count) in index order, by one wave (call from all 64 lanes of it): an element that is +0.0 or
+// (+0.0) + the NONZERO elements of v[0 .. count) in index order, by one wave (call from all 64 lanes of it): an element that is +0.0 or
 // -0.0 never changes a running sum that starts at +0.0 (x + (+-0) = x, and such a sum is never -0), so leaving the zeros out gives the
 // bits of the sum over all.  The nonzero ones are first moved to the front of v, in order (ballot + prefix count per 64-element chunk;
 // a chunk is in registers before anything is written at or below it), then added by seq_fold.  v is destroyed.
-__device__ __forceinline__ double wave_fold_nonzero(lds_f64 *v, int count, double acc) {
+__device__ __forceinline__ double wave_fold_nonzero(lds_f64 *v, int count) {
     const int lane = threadIdx.x & 63;
     int base = 0;
     double x = lane < count ? v[lane] : 0.0;
@@ -243,7 +252,7 @@ __device__ __forceinline__ double wave_fold_nonzero(lds_f64 *v, int count, doubl
         if (nz) v[pos] = xc;
         base += __popcll(mask);
     }
-    return seq_fold(v, base, acc);
+    return seq_fold(v, base);
 }
 // inf-norm of a vector, or of a .* b when b != NULL (lin_alg.c:107-140: NaN never wins)
 __device__ double norm_inf(const double *a, const double *b, int n, double *sm) {
@@ -293,11 +302,8 @@ __device__ void spmv_rows_staged(int nrows, const int *rp, const int *ci, const 
     if (nnz > cap) { spmv_rows(nrows, rp, ci, val, x, y); return; }
     FOR_T(k, nnz) scr[k] = val[k] * x[ci[k]];
     SYNC;
-    FOR_T(r, nrows) {
-        double s = 0.0;
-        for (int k = rp[r]; k < rp[r + 1]; k++) s += scr[k];
-        y[r] = s;
-    }
+    const lds_f64 *sl = (const lds_f64 *)scr;       // (the union region: LDS)
+    FOR_T(r, nrows) { const int k0 = rp[r]; y[r] = seq_fold(sl + k0, rp[r + 1] - k0); }
 }
 // two products of the same vector (Q x and A x) with one barrier between the phases
 __device__ void spmv2_rows_staged(int n1, const int *rp1, const int *ci1, const double *val1, double *y1, int n2, const int *rp2, const int *ci2,
@@ -308,8 +314,9 @@ __device__ void spmv2_rows_staged(int n1, const int *rp1, const int *ci1, const 
     FOR_T(k, nnz1) scr[k] = val1[k] * x[ci1[k]];
     FOR_T(k, nnz2) s2[k] = val2[k] * x[ci2[k]];
     SYNC;
-    FOR_T(r, n1) { double s = 0.0; for (int k = rp1[r]; k < rp1[r + 1]; k++) s += scr[k]; y1[r] = s; }
-    FOR_T(r, n2) { double s = 0.0; for (int k = rp2[r]; k < rp2[r + 1]; k++) s += s2[k]; y2[r] = s; }
+    const lds_f64 *sl1 = (const lds_f64 *)scr, *sl2 = (const lds_f64 *)s2;
+    FOR_T(r, n1) { const int k0 = rp1[r]; y1[r] = seq_fold(sl1 + k0, rp1[r + 1] - k0); }
+    FOR_T(r, n2) { const int k0 = rp2[r]; y2[r] = seq_fold(sl2 + k0, rp2[r + 1] - k0); }
 }
 
 // ---- Ruiz + cost scaling (scaling.c:24-91) ----------------------------------------------------------
@@ -738,7 +745,7 @@ __device__ __forceinline__ double small_linesearch_impl(SmallQP &P, double *V[],
     // 2m (+0.0 for the others, 30 cycles per readlane step) took 9.5 us.
     if (threadIdx.x < 4) {
         const lds_f64 *G = threadIdx.x == 0 ? G0 : threadIdx.x == 1 ? G1 : threadIdx.x == 2 ? G2 : G3;
-        sm[24 + threadIdx.x] = seq_fold(G, (threadIdx.x & 1) ? cn : cm, 0.0);
+        sm[24 + threadIdx.x] = seq_fold(G, (threadIdx.x & 1) ? cn : cm);
     } else if (threadIdx.x >= 64 && threadIdx.x < 192) {
         const int lane = threadIdx.x & 63, second = (threadIdx.x >> 6) - 1;
         lds_f64 *cb = (lds_f64 *)skey + (size_t)second * m;
@@ -758,7 +765,7 @@ __device__ __forceinline__ double small_linesearch_impl(SmallQP &P, double *V[],
             base += __popcll(mask);
             if (!second) nLc += __popcll(__ballot(fc & 1));
         }
-        if (base <= m) acc = seq_fold(cb, base, 0.0);
+        if (base <= m) acc = seq_fold(cb, base);
         else {                                       // (bounds with l > u somewhere: more than m elements in J -- add them lane by lane)
 #pragma nounroll
             for (int c = 0; c < M2; c += 64) {
@@ -1116,9 +1123,10 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
                         FOR_T(k, nzQ) s2[k] = P.Qval[k] * dxs[P.Qci[k]];
                         FOR_T(k, nzA) s3[k] = P.Aval[k] * dxs[P.Aci[k]];
                         SYNC;
-                        FOR_T(r, n) { double sacc = 0.0; for (int k = P.Trp[r]; k < P.Trp[r + 1]; k++) sacc += s1[k]; Atdy[r] = sacc; }
-                        FOR_T(r, n) { double sacc = 0.0; for (int k = P.Qrp[r]; k < P.Qrp[r + 1]; k++) sacc += s2[k]; Qdx[r] = sacc; }
-                        FOR_T(r, m) { double sacc = 0.0; for (int k = rp_s[r]; k < rp_s[r + 1]; k++) sacc += s3[k]; Adx[r] = sacc; }
+                        const lds_f64 *l1 = (const lds_f64 *)s1, *l2 = (const lds_f64 *)s2, *l3 = (const lds_f64 *)s3;
+                        FOR_T(r, n) { const int k0 = P.Trp[r]; Atdy[r] = seq_fold(l1 + k0, P.Trp[r + 1] - k0); }
+                        FOR_T(r, n) { const int k0 = P.Qrp[r]; Qdx[r] = seq_fold(l2 + k0, P.Qrp[r + 1] - k0); }
+                        FOR_T(r, m) { const int k0 = rp_s[r]; Adx[r] = seq_fold(l3 + k0, rp_s[r + 1] - k0); }
                         SYNC;                                     // (the staged products sit where the bound terms are written next)
                     } else {
                         if (act_p) { spmv_rows_staged(n, P.Trp, P.Tci, P.Tval, dy, Atdy, Klds, ucap); SYNC; }
@@ -1152,8 +1160,8 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
                 lds_f64 *Rm = red_next(RB);
                 max4_post(mx_at, mx_q, viol_f, 0.0, Rm);
                 SYNC;
-                if (act_p && threadIdx.x < 64) { const double oobs = wave_fold_nonzero((lds_f64 *)ls_delta, 2 * m, 0.0); if (threadIdx.x == 0) sm[18] = oobs; }
-                if (act_d && threadIdx.x >= 64 && threadIdx.x < 128) { const double prod = seq_fold((const lds_f64 *)gbuf, cntq, 0.0); if (threadIdx.x == 64) sm[19] = prod; }
+                if (act_p && threadIdx.x < 64) { const double oobs = wave_fold_nonzero((lds_f64 *)ls_delta, 2 * m); if (threadIdx.x == 0) sm[18] = oobs; }
+                if (act_d && threadIdx.x >= 64 && threadIdx.x < 128) { const double prod = seq_fold((const lds_f64 *)gbuf, cntq); if (threadIdx.x == 64) sm[19] = prod; }
                 SYNC;
                 const double oob = sm[18], qdx = sm[19];
                 double nat, nq, viol_m, d4;
