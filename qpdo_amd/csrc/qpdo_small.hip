@@ -59,6 +59,7 @@ struct SmallQP {
     long newton_passes, factor_count;
     long long *prof;                         // optional: per-phase wall-clock ticks (diagnostic runs only)
     struct SmallRes *res;                    // resident mode (latency kernel only): see SmallRes; NULL in a batch
+    unsigned batch_vec_off;                  // a batch through the latency kernel: byte offset of the vector workspace inside the dynamic LDS (0: global memory)
 };
 // ---- resident mode (qpdo_solve of ONE small workspace through the latency kernel, qdev_small_resident_*): the matrices, q, l, u are the
 // workspace's own device arrays, already scaled by qpdo_setup (bit-identical to the oracle's scaling), so the kernel skips its Ruiz
@@ -930,12 +931,12 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
             mode = __builtin_amdgcn_readfirstlane(Rg->mode);
             // One workspace has the CU to itself: its ~30 work vectors move from global memory (L2-resident, but every barrier that follows a
             // vector update waits for the stores' round trip) into LDS when they fit beside the factor.  Same operations on the same values.
-            const unsigned voff = (unsigned)__builtin_amdgcn_readfirstlane((int)Rg->lds_vec_off);
-            if (voff) {
-                P.nv = uni_ptr((double *)((char *)dyn + voff));
-                P.mv = P.nv + (size_t)NV_COUNT * P.n;
-                P.iv = (int *)(P.mv + (size_t)MV_COUNT * P.m);
-            }
+        }
+        const unsigned voff = (unsigned)__builtin_amdgcn_readfirstlane((int)(Rg ? Rg->lds_vec_off : Pg.batch_vec_off));
+        if (voff) {
+            P.nv = uni_ptr((double *)((char *)dyn + voff));
+            P.mv = P.nv + (size_t)NV_COUNT * P.n;
+            P.iv = (int *)(P.mv + (size_t)MV_COUNT * P.m);
         }
     }
 #undef UNI_PTR
@@ -1459,6 +1460,7 @@ static int pinned_reserve(char **buf, size_t *cap, size_t need) {
 // else the linesearch scratch alone; the kernel's layout, k_small_solve).  klds_ok (optional out): 1 when K lives in LDS; passing
 // NULL sizes the K-in-global-memory layout.
 static const size_t SMALL_LDS_BUDGET = 160 * 1024 - 1024;                // static LDS: reduction scratch only
+static const bool SMALL_BATCH_LAT_DEFAULT = false;                       // (see slot_submit)
 static size_t small_lds_bytes(size_t nmax, size_t mmax, int *klds_ok, size_t *union_bytes = nullptr) {
     size_t lds = 8 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
     const size_t kbytes = nmax * (nmax + 1) / 2 * 8;
@@ -1564,7 +1566,6 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
             for (long i = 0; i < count; i++) hp[(size_t)i].prof = S.dprof + i * PH_COUNT;
         }
     }
-    SHIP(hipMemcpyAsync(S.dprobs, hp, (size_t)count * sizeof(SmallQP), hipMemcpyHostToDevice, S.stream));
     {
         size_t nmax = 1, mmax = 0;
         for (long i = 0; i < count; i++) { if (items[i].data->n > nmax) nmax = items[i].data->n; if (items[i].data->m > mmax) mmax = items[i].data->m; }
@@ -1574,9 +1575,23 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
         if (const char *kg = getenv("QPDO_SMALL_K_GLOBAL")) { if (atoi(kg) && klds_ok) { klds_ok = 0; lds = small_lds_bytes(nmax, mmax, nullptr, &ubytes); } }      // occupancy experiments
         SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(budget)));
         if (const char *pad = getenv("QPDO_SMALL_LDS_MIN")) { const size_t v = (size_t)atol(pad); if (v > lds && v <= budget) lds = v; }   // occupancy experiments
-        SHIP(hipEventRecord(S.ev0, S.stream));
         const int kflags = klds_ok | ((int)(ubytes / 8) << 1);       // (the LDS_MIN padding experiment below the launch only grows the tail)
-        hipLaunchKernelGGL(k_small_solve, dim3((unsigned)count), dim3(SM_THREADS), lds, S.stream, S.dprobs, (int)count, *settings, kflags);
+        // Which kernel (QPDO_SMALL_BATCH_KERNEL=wide|lat overrides).  "lat": the latency variant -- one workgroup per CU with 256 VGPRs and
+        // the item's ~30 work vectors in LDS beside the factor -- whenever everything fits; "wide": two workgroups per CU at 128 VGPRs, vectors
+        // in global memory.  Same operations on the same values either way.
+        const size_t voff = (lds + 15) & ~(size_t)15;
+        const size_t vbytes = ((size_t)NV_COUNT * nmax + (size_t)MV_COUNT * mmax) * 8 + 3 * mmax * 4 + 16;
+        const char *bk = getenv("QPDO_SMALL_BATCH_KERNEL");
+        const bool lat_fits = klds_ok && voff + vbytes <= budget;
+        const bool use_lat = lat_fits && !(bk && !strcmp(bk, "wide")) && (bk ? !strcmp(bk, "lat") : SMALL_BATCH_LAT_DEFAULT);
+        if (use_lat) {
+            for (long i = 0; i < count; i++) hp[(size_t)i].batch_vec_off = (unsigned)voff;
+            SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve_lat), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(budget)));
+        }
+        SHIP(hipMemcpyAsync(S.dprobs, hp, (size_t)count * sizeof(SmallQP), hipMemcpyHostToDevice, S.stream));
+        SHIP(hipEventRecord(S.ev0, S.stream));
+        if (use_lat) hipLaunchKernelGGL(k_small_solve_lat, dim3((unsigned)count), dim3(SM_THREADS), voff + vbytes, S.stream, S.dprobs, (int)count, *settings, kflags);
+        else hipLaunchKernelGGL(k_small_solve, dim3((unsigned)count), dim3(SM_THREADS), lds, S.stream, S.dprobs, (int)count, *settings, kflags);
         SHIP(hipEventRecord(S.ev1, S.stream));
     }
     SHIP(hipGetLastError());
