@@ -533,6 +533,136 @@ __device__ __forceinline__ void small_factor4_t(int n, double *__restrict__ K, d
     }
     if (k < n) small_factor_t<PACKED>(n, K, L0, T0, L1, T1, k, off0);
 }
+// The four-column factorization with LOOK-AHEAD (round 4; K packed in LDS; NR = rows per lane and trip -- 2 was measured slower: spills).  In small_factor4_t every thread factors the leading 4 x 4
+// block itself -- four dependent IEEE divisions, ~200 fp64 instructions, in all eight waves: ~2000 issue cycles per SIMD and step, on the
+// critical path between two barriers -- and the trailing update waits for it.  Here wave 0 alone works one step ahead: during step k it
+// applies step k to columns k+4 .. k+7 (all rows), factors their 4 x 4 block, scales the four columns and leaves l and l*d of step k+4 in
+// the OTHER of two buffers, while waves 1 .. 7 apply step k to the columns from k+8 on; one barrier per step.  Every element receives the
+// subtractions of steps k, k+1, ... in ascending order with the operands of small_factor4_t -- which wave makes them and when is all
+// that changes -- so the same bits.  F: 16n doubles (two buffers of l and l*d of four columns).  The last n mod 4 columns go through the
+// two-column code.
+template <int NR>
+__device__ __forceinline__ void factor4_block_and_scale(int n, int k, lds_f64 *K, int off0, lds_f64 *Fn, int lane) {
+    // columns k .. k+3 have received every earlier step: factor the 4 x 4 block (every lane alike), scale rows >= k+4 (lane by lane)
+    lds_f64 *L0 = Fn, *L1 = Fn + n, *L2 = Fn + 2 * (size_t)n, *L3 = Fn + 3 * (size_t)n;
+    lds_f64 *T0 = Fn + 4 * (size_t)n, *T1 = Fn + 5 * (size_t)n, *T2 = Fn + 6 * (size_t)n, *T3 = Fn + 7 * (size_t)n;
+    const int off1 = off0 + (n - k - 1), off2 = off1 + (n - k - 2), off3 = off2 + (n - k - 3);
+    const double d0 = K[off0 + k], inv0 = 1.0 / d0;
+    const double l10 = K[off0 + k + 1] * inv0, l20 = K[off0 + k + 2] * inv0, l30 = K[off0 + k + 3] * inv0;
+    const double t10 = l10 * d0, t20 = l20 * d0, t30 = l30 * d0;
+    const double d1 = K[off1 + k + 1] - l10 * t10, inv1 = 1.0 / d1;
+    const double l21 = (K[off1 + k + 2] - l20 * t10) * inv1, l31 = (K[off1 + k + 3] - l30 * t10) * inv1;
+    const double t21 = l21 * d1, t31 = l31 * d1;
+    const double d2 = (K[off2 + k + 2] - l20 * t20) - l21 * t21, inv2 = 1.0 / d2;
+    const double l32 = ((K[off2 + k + 3] - l30 * t20) - l31 * t21) * inv2, t32 = l32 * d2;
+    const double d3 = ((K[off3 + k + 3] - l30 * t30) - l31 * t31) - l32 * t32;
+    const double inv3 = 1.0 / d3;
+    if constexpr (NR == 1) {
+        for (int i = k + 4 + lane; i < n; i += 64) {
+            const double l0 = K[off0 + i] * inv0;
+            const double v1 = K[off1 + i] - l0 * t10;
+            const double l1 = v1 * inv1;
+            const double v2 = (K[off2 + i] - l0 * t20) - l1 * t21;
+            const double l2 = v2 * inv2;
+            const double v3 = ((K[off3 + i] - l0 * t30) - l1 * t31) - l2 * t32;
+            const double l3 = v3 * inv3;
+            K[off0 + i] = l0; K[off1 + i] = l1; K[off2 + i] = l2; K[off3 + i] = l3;
+            L0[i] = l0; L1[i] = l1; L2[i] = l2; L3[i] = l3;
+            T0[i] = l0 * d0; T1[i] = l1 * d1; T2[i] = l2 * d2; T3[i] = l3 * d3;
+        }
+    } else
+    // two rows per lane and trip (i, i + 64): two independent chains of ten dependent operations side by side
+    for (int i = k + 4 + lane; i < n; i += 128) {
+        const int ib = i + 64 < n ? i + 64 : i;       // (clamped: the second row's results are dropped when it does not exist)
+        const double ka0 = K[off0 + i], ka1 = K[off1 + i], ka2 = K[off2 + i], ka3 = K[off3 + i];
+        const double kb0 = K[off0 + ib], kb1 = K[off1 + ib], kb2 = K[off2 + ib], kb3 = K[off3 + ib];
+        const double l0 = ka0 * inv0, m0 = kb0 * inv0;
+        const double v1 = ka1 - l0 * t10, u1 = kb1 - m0 * t10;
+        const double l1 = v1 * inv1, m1 = u1 * inv1;
+        const double v2 = (ka2 - l0 * t20) - l1 * t21, u2 = (kb2 - m0 * t20) - m1 * t21;
+        const double l2 = v2 * inv2, m2 = u2 * inv2;
+        const double v3 = ((ka3 - l0 * t30) - l1 * t31) - l2 * t32, u3 = ((kb3 - m0 * t30) - m1 * t31) - m2 * t32;
+        const double l3 = v3 * inv3, m3 = u3 * inv3;
+        K[off0 + i] = l0; K[off1 + i] = l1; K[off2 + i] = l2; K[off3 + i] = l3;
+        L0[i] = l0; L1[i] = l1; L2[i] = l2; L3[i] = l3;
+        T0[i] = l0 * d0; T1[i] = l1 * d1; T2[i] = l2 * d2; T3[i] = l3 * d3;
+        if (ib != i) {
+            K[off0 + ib] = m0; K[off1 + ib] = m1; K[off2 + ib] = m2; K[off3 + ib] = m3;
+            L0[ib] = m0; L1[ib] = m1; L2[ib] = m2; L3[ib] = m3;
+            T0[ib] = m0 * d0; T1[ib] = m1 * d1; T2[ib] = m2 * d2; T3[ib] = m3 * d3;
+        }
+    }
+    if (lane == 0) {                                  // (read by every lane above: the wave's LDS operations execute in program order)
+        K[off0 + k + 1] = l10; K[off0 + k + 2] = l20; K[off0 + k + 3] = l30;
+        K[off1 + k + 1] = d1;  K[off1 + k + 2] = l21; K[off1 + k + 3] = l31;
+        K[off2 + k + 2] = d2;  K[off2 + k + 3] = l32; K[off3 + k + 3] = d3;
+    }
+}
+// step k applied to NC columns jj[u] (rows from row0 on, this wave's lanes): K(i,j) -= l_i0 t_j0, -= l_i1 t_j1, -= l_i2 t_j2, -= l_i3 t_j3
+template <int NC, int NR>
+__device__ __forceinline__ void factor4_apply(int n, lds_f64 *K, const lds_f64 *Fc, const int (&jj)[NC], int row0, int lane) {
+    const lds_f64 *L0 = Fc, *L1 = Fc + n, *L2 = Fc + 2 * (size_t)n, *L3 = Fc + 3 * (size_t)n;
+    const lds_f64 *T0 = Fc + 4 * (size_t)n, *T1 = Fc + 5 * (size_t)n, *T2 = Fc + 6 * (size_t)n, *T3 = Fc + 7 * (size_t)n;
+    int off[NC]; double tj[NC][4];
+#pragma unroll
+    for (int u = 0; u < NC; u++) {
+        const int jc = jj[u] < n ? jj[u] : n - 1;
+        tj[u][0] = T0[jc]; tj[u][1] = T1[jc]; tj[u][2] = T2[jc]; tj[u][3] = T3[jc];
+        off[u] = jc * n - (jc * (jc + 1)) / 2;
+    }
+    // NR rows per lane and trip (i, i + 64, ...): their loads are issued together and their chains run side by side
+    for (int i0 = row0 + lane; i0 < n; i0 += 64 * NR) {
+        int ir[NR]; double a[NR][4], v[NR][NC];
+#pragma unroll
+        for (int r = 0; r < NR; r++) { const int i = i0 + 64 * r; ir[r] = i < n ? i : i0; }      // (clamped: a row that does not exist stores nothing)
+#pragma unroll
+        for (int r = 0; r < NR; r++) { a[r][0] = L0[ir[r]]; a[r][1] = L1[ir[r]]; a[r][2] = L2[ir[r]]; a[r][3] = L3[ir[r]]; }
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+#pragma unroll
+            for (int u = 0; u < NC; u++) v[r][u] = K[off[u] + ir[r]];      // (jc <= n-1, i <= n-1: inside the packed array whatever the guard says)
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+#pragma unroll
+            for (int u = 0; u < NC; u++) if (jj[u] < n && ir[r] >= jj[u] && (r == 0 || i0 + 64 * r < n)) {
+                double w = v[r][u] - a[r][0] * tj[u][0];
+                w = w - a[r][1] * tj[u][1];
+                w = w - a[r][2] * tj[u][2];
+                K[off[u] + ir[r]] = w - a[r][3] * tj[u][3];
+            }
+    }
+}
+template <int NR>
+__device__ __forceinline__ void small_factor4_la(int n, double *Kg, double *Fg) {
+    lds_f64 *K = (lds_f64 *)Kg, *F = (lds_f64 *)Fg;
+    const int li = threadIdx.x & 63, wj = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int off0 = 0, k = 0, cur = 0;
+    if (n >= 4 && wj == 0) factor4_block_and_scale<NR>(n, 0, K, 0, F, li);
+    SYNC;
+    for (; k + 3 < n; k += 4) {
+        const lds_f64 *Fc = F + (size_t)cur * 8 * n; lds_f64 *Fn = F + (size_t)(cur ^ 1) * 8 * n;
+        const int off4 = off0 + (n - k - 1) + (n - k - 2) + (n - k - 3) + (n - k - 4);       // off(k+4)
+        const bool ahead = (k + 7 < n) && nw > 1;     // a whole next block: wave 0 takes it one step ahead
+        if (ahead && wj == 0) {
+            const int jj[4] = { k + 4, k + 5, k + 6, k + 7 };
+            factor4_apply<4, NR>(n, K, Fc, jj, k + 4, li);
+            factor4_block_and_scale<NR>(n, k + 4, K, off4, Fn, li);
+        } else {
+            const int first = ahead ? k + 8 : k + 4, w0 = ahead ? wj - 1 : wj, nwt = ahead ? nw - 1 : nw;
+            for (int j0 = first + w0; j0 < n; j0 += 4 * nwt) {
+                const int jj[4] = { j0, j0 + nwt, j0 + 2 * nwt, j0 + 3 * nwt };
+                factor4_apply<4, NR>(n, K, Fc, jj, k + 4, li);
+            }
+        }
+        SYNC;
+        if (!ahead && k + 7 < n) {                     // (one wave only: nobody worked ahead)
+            if (wj == 0) factor4_block_and_scale<NR>(n, k + 4, K, off4, Fn, li);
+            SYNC;
+        }
+        off0 = off4; cur ^= 1;
+    }
+    if (k < n) small_factor_t<true>(n, Kg, Fg, Fg + 4 * (size_t)n, Fg + n, Fg + 5 * (size_t)n, k, off0);
+}
 // x lives in LDS (xs) for the duration of the solve.  Two columns per barrier, as in the factorization: every thread applies step j
 // to entry j+1 itself (x_{j+1} = xs[j+1] - L(j+1,j) x_j, the subtraction the column sweep would have made), then each entry receives
 // the subtractions of column j and of column j+1 in that order -- the operations of the one-column loop, so the same bits.
@@ -901,7 +1031,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
     __shared__ double sm[32];
     __shared__ double red_scr[64];                    // two banks of reduction partials (RedBank)
     extern __shared__ __attribute__((aligned(16))) double dyn[];
-    // dynamic LDS: [xs: n][colbuf: n][tk: 2n][4n more for the four-column factorization][gbuf][d_s: m][rp_s: m+1][U], U = one region shared by the packed factor K
+    // dynamic LDS: [xs: n][colbuf: n][tk: 2n][12n more for the four-column factorization with look-ahead][gbuf][d_s: m][rp_s: m+1][U], U = one region shared by the packed factor K
     // (if it fits) and the linesearch scratch (delta, alpha, sort keys, sort indices, flags).  The linesearch of a
     // pass runs after the pass's solve, so it may overwrite K: the factor is then rebuilt in the next pass instead
     // of being reused when the weights did not change -- the same bits, a little more work -- and the workgroup needs
@@ -957,7 +1087,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
            *res_prim_old = V[MV_RPOLD], *res_prim_in = V[MV_RPI], *dy = V[MV_DY], *Adx = V[MV_ADX], *dw = V[MV_DW], *E = V[MV_E],
            *Einv = V[MV_EINV], *ats = V[MV_ATS], *tm = V[MV_T], *dwf = V[MV_DWF];
     int *active = P.iv, *active_old = P.iv + m, *changed = P.iv + 2 * m;
-    double *xs = dyn, *colbuf = dyn + n, *tk = dyn + 2 * (size_t)n, *gbuf = dyn + 8 * (size_t)n;      // dyn .. dyn + 8n: l and l*d of four columns during a factorization
+    double *xs = dyn, *colbuf = dyn + n, *tk = dyn + 2 * (size_t)n, *gbuf = dyn + 16 * (size_t)n;     // dyn .. dyn + 16n: l and l*d of four columns during a factorization, two buffers (look-ahead)
     double *d_s = gbuf + (((size_t)(n > m ? n : m) / 4 + 4 + 1) & ~(size_t)1);
     int *rp_s = (int *)(d_s + m);
     double *Klds = (double *)(rp_s + (((size_t)m + 1 + 3) & ~(size_t)3));          // start of U
@@ -1268,7 +1398,11 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
                 FOR_T(i, m) dwf[i] = dw[i];
                 fact_sigma_f = sigma_f; have_fact = 1;
                 small_assemble(P, kv, dw, sigma_f, rp_s, d_s); PH(PH_ASM);
-                if (klds_ok) small_factor4_t<true>(n, Klds, dyn); else small_factor4_t<false>(n, P.K, dyn);
+                if (klds_ok) {
+                    // look-ahead in the latency kernel only (80 -> 71 us at n = 120); in the wide kernel, two workgroups per CU at 128 VGPRs, it gains
+                    // nothing at max_iter 300 and its registers cost the stalled passes 5 % (measured both ways)
+                    if constexpr (LAT) small_factor4_la<1>(n, Klds, dyn); else small_factor4_t<true>(n, Klds, dyn);
+                } else small_factor4_t<false>(n, P.K, dyn);
                 PH(PH_FACTOR); factor_valid = 1; nfactor++;
                 // The factor shares its LDS region with the linesearch scratch, so it does not survive the pass.  A copy in the
                 // item's global K buffer (58 KB at n = 120, L2-resident) lets the next passes RESTORE it while (sigma_f, d) stay
@@ -1462,7 +1596,7 @@ static int pinned_reserve(char **buf, size_t *cap, size_t need) {
 static const size_t SMALL_LDS_BUDGET = 160 * 1024 - 1024;                // static LDS: reduction scratch only
 static const bool SMALL_BATCH_LAT_DEFAULT = false;                       // (see slot_submit)
 static size_t small_lds_bytes(size_t nmax, size_t mmax, int *klds_ok, size_t *union_bytes = nullptr) {
-    size_t lds = 8 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
+    size_t lds = 16 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
     const size_t kbytes = nmax * (nmax + 1) / 2 * 8;
     size_t np2 = 1; while (np2 < 2 * mmax) np2 <<= 1;
     size_t lsbytes = 2 * mmax * (8 + 8) + np2 * (8 + 4) + ((2 * mmax + 15) & ~(size_t)15);   // delta, alpha, keys, indices, flags
