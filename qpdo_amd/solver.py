@@ -424,6 +424,19 @@ class Batch:
         self.kernel_seconds = float(lib().qpdo_amd_batch_kernel_seconds())
         return self.results(), int(failed)
 
+    def info_view(self):
+        """The items' QPDOInfo fields as ONE numpy structured array over the item array itself (no copy, no per-item Python work):
+        info_view()["iterations"], ["oterations"], ["status_val"], ["res_prim_norm"] ... -- what a caller that streams batches
+        looks at per batch; x and y of item i are self.outs[i] either way.  results() builds the per-item dicts from the same memory."""
+        base = BatchItem.info.offset
+        names, formats, offsets = [], [], []
+        for f, t in QPDOInfo._fields_:
+            if f == "status":
+                continue
+            names.append(f); formats.append(np.dtype(t)); offsets.append(base + getattr(QPDOInfo, f).offset)
+        dt = np.dtype(dict(names=names, formats=formats, offsets=offsets, itemsize=C.sizeof(BatchItem)))
+        return np.frombuffer(self.items, dtype=dt, count=len(self.outs))
+
     def results(self):
         """list of dicts (info, x, y) from the items' output fields (after run(), or after BatchStream.wait)"""
         names = [f for f, _ in QPDOInfo._fields_]
@@ -459,13 +472,14 @@ class BatchStream:
         self._inflight[t] = (batch, settings)
         return t
 
-    def wait(self, ticket):
+    def wait(self, ticket, results=True):
+        """results=False: skip building the per-item dicts (the outputs are in the Batch: info_view(), outs)"""
         batch, _ = self._inflight.pop(ticket)
         ks = C.c_double(0.0)
         if lib().qpdo_amd_batch_stream_wait(self._h, int(ticket), C.byref(ks)) != 0:
             raise RuntimeError("qpdo_amd_batch_stream_wait failed: " + lib().qpdo_amd_last_error().decode())
         batch.kernel_seconds = float(ks.value)
-        return batch.results(), float(ks.value)
+        return (batch.results() if results else None), float(ks.value)
 
     def close(self):
         if self._h:
