@@ -86,6 +86,21 @@ def test_no_cpu_fallback_without_device(capfd):
     assert "no HIP device" in capfd.readouterr().out
 
 
+def test_batch_info_view_reads_the_item_array_in_place():
+    """Batch.info_view(): one numpy view over the QPDOAmdBatchItem array the C side fills -- the same memory results() reads item by item"""
+    B = solver.Batch([problems.config_qp("C3", i) for i in range(6)])
+    for i in range(6):
+        inf = B.items[i].info
+        inf.iterations, inf.oterations, inf.status_val, inf.objective, inf.res_prim_norm = 10 + i, i, (1 if i % 2 else -5), 0.25 * i, 1e-7 * (i + 1)
+    v, r = B.info_view(), B.results()
+    assert len(v) == 6
+    for i in range(6):
+        for f in ("iterations", "oterations", "status_val", "objective", "res_prim_norm", "res_dual_norm", "solve_time"):
+            assert v[f][i] == r[i]["info"][f]
+    B.items[3].info.iterations = 77                       # a view, not a copy
+    assert v["iterations"][3] == 77
+
+
 def test_generator_is_deterministic_and_psd():
     a, b = problems.random_qp(3, 60, 90, 0.1), problems.random_qp(3, 60, 90, 0.1)
     assert (a["A"] != b["A"]).nnz == 0 and (a["Q"] != b["Q"]).nnz == 0 and np.array_equal(a["q"], b["q"])

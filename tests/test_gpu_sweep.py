@@ -96,9 +96,13 @@ def test_pcg_without_proximal_term_falls_back_to_the_dense_solver_not_to_an_erro
     assert r["stats"]["pcg_dense_fallbacks"] >= 1
 
 
-def test_fused_batch_sweep_is_bit_identical(gpu_required):
+@pytest.mark.parametrize("kernel", ["wide", "lat"])
+def test_fused_batch_sweep_is_bit_identical(kernel, gpu_required, monkeypatch):
     """the one-workgroup-per-QP kernel on the same 120 varied instances (one launch): operation order equals the
-    oracle's, so x, y, objective and residual norms must match bit for bit (NaN-filled outputs for the certificates)"""
+    oracle's, so x, y, objective and residual norms must match bit for bit (NaN-filled outputs for the certificates).
+    Both launch shapes of a batch: "wide" (default: two workgroups per CU, work vectors in global memory) and "lat"
+    (QPDO_SMALL_BATCH_KERNEL=lat: the latency kernel qpdo_solve uses, one workgroup per CU, work vectors in LDS)."""
+    monkeypatch.setenv("QPDO_SMALL_BATCH_KERNEL", kernel)
     probs = [_instance(i)[0] for i in range(120)]
     res, failed = solver.solve_batch(probs, verbose=0, max_iter=300)
     assert failed == 0
