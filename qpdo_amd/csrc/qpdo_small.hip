@@ -782,16 +782,19 @@ __device__ void small_ldl_solve(SmallQP &P, const KView &kv, const double *b, do
 // double as the exchange buffer: write, barrier, read, barrier), j < 64 is a lane shuffle without a barrier -- 45 of the 55 stages at
 // np2 = 1024.  The network and every comparison are those of the all-LDS version it replaces (one barrier per stage): the same
 // permutation, i.e. the stable order by (t, index) of the reference's qsort.  Ends with the sorted arrays in skey / sidx.
-template <int R>
+// PRE: the first M2 (key, index) pairs are already in skey / sidx (a compacted subset of the candidates); the rest is padding.
+template <int R, bool PRE = false>
 __device__ __forceinline__ void small_sort_regs(int np2, int M2, const lds_f64 *ls_alpha, const lds_f64 *ls_delta, lds_u64 *skey, lds_u32 *sidx) {
     u64 key[R]; u32 idx[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int e = (int)threadIdx.x + SM_THREADS * r;
-        u64 kv = ~0ull;
-        if (e < M2) { const double t = ls_alpha[e] / ls_delta[e]; if (t > 0) kv = (u64)__double_as_longlong(t); }
-        key[r] = kv; idx[r] = (u32)e;
+        u64 kv = ~0ull; u32 iv = (u32)e;
+        if constexpr (PRE) { if (e < M2) { kv = skey[e]; iv = sidx[e]; } }
+        else if (e < M2) { const double t = ls_alpha[e] / ls_delta[e]; if (t > 0) kv = (u64)__double_as_longlong(t); }
+        key[r] = kv; idx[r] = iv;
     }
+    if constexpr (PRE) SYNC;                            // (the arrays double as the exchange buffer below)
     for (int k = 2; k <= np2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             if (j >= SM_THREADS) {                     // partner in this thread: elements r and r ^ (j / 512)
@@ -938,8 +941,72 @@ __device__ __forceinline__ double small_linesearch_impl(SmallQP &P, double *V[],
         PHL(PH_LS_WALK);
         return -b / a;                                 // (the caller's next barrier comes before anything writes sm or the scratch again)
     }
-    // the walk goes on: stable order by (t, index) = the reference's qsort
     int np2 = 1; while (np2 < M2) np2 <<= 1;
+    // The walk goes on.  It rarely goes far: counted on the C3 batch (instrumented oracle, 4682 walks), 30 breakpoints on average of 435
+    // candidates, and in 95 % of the walks it ends below 1.5 tau0, tau0 = -b/a the root before any breakpoint is crossed.  So first the
+    // candidates with t <= 1.5 tau0 alone (97 on average): compacted in index order, sorted by (t, index) -- a 64 / 128 / 256-element
+    // network instead of the 1024-element one -- and walked; they are exactly the first c elements of the full order, so a walk that stops
+    // inside them has seen what the full sort would have shown it.  One that runs off their end starts again on the full sort below.
+    if (np2 >= 1024) {
+        const double tlim = 1.5 * (-b / a);
+        if (tlim > 0.0 && tlim < 1e300) {
+            const u64 klim = (u64)__double_as_longlong(tlim);
+            const int per0 = (M2 + SM_THREADS - 1) / SM_THREADS, wv = threadIdx.x >> 6;
+            u64 kk[4]; bool in[4]; int pre[4];
+            __attribute__((address_space(3))) int *cnts = (__attribute__((address_space(3))) int *)gbuf;      // 4 x 8 wave counts (the group sums are spent)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int e = (int)threadIdx.x + SM_THREADS * r;
+                kk[r] = ~0ull; in[r] = false;
+                if (r < per0 && e < M2 && (jflag[e] & 1)) { const double t = ls_alpha[e] / ls_delta[e]; kk[r] = (u64)__double_as_longlong(t); in[r] = kk[r] <= klim; }
+                const u64 mask = __ballot(in[r]);
+                pre[r] = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if ((threadIdx.x & 63) == 0) cnts[8 * r + wv] = __popcll(mask);
+            }
+            SYNC;
+            int c = 0, off[4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                for (int w2 = 0; w2 < SM_THREADS / 64; w2++) { if (w2 == wv) off[r] = c; c += cnts[8 * r + w2]; }
+            if (c <= 256) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (in[r]) { skey[off[r] + pre[r]] = kk[r]; sidx[off[r] + pre[r]] = (u32)((int)threadIdx.x + SM_THREADS * r); }
+                SYNC;
+                const int np2p = c <= 64 ? 64 : c <= 128 ? 128 : 256;
+                small_sort_regs<1, true>(np2p, c, ls_alpha, ls_delta, skey, sidx);
+                lds_f64 *D2 = (lds_f64 *)(skey + 256), *A2 = (lds_f64 *)(skey + 512);       // (np2 >= 1024 keys: room behind the subset)
+                if ((int)threadIdx.x < c) { const u32 iz = sidx[threadIdx.x]; D2[threadIdx.x] = ls_delta[iz]; A2[threadIdx.x] = ls_alpha[iz]; }
+                SYNC;
+                if (threadIdx.x == 0) {
+                    double aw = a, bw = b;
+                    int i = 0; bool found = false;
+#pragma nounroll
+                    while (i < c - 1 && !found) {
+                        const int left = c - 1 - i;
+                        double dl[4], al[4], tn[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (u < left) { dl[u] = D2[i + u]; al[u] = A2[i + u]; tn[u] = __longlong_as_double((long long)skey[i + u + 1]); }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (u < left && !found) {
+                            if (dl[u] > 0) { aw = aw + dl[u] * dl[u]; bw = bw - dl[u] * al[u]; } else { aw = aw - dl[u] * dl[u]; bw = bw + dl[u] * al[u]; }
+                            i++;
+                            if (bw + aw * tn[u] > 0) found = true;
+                        }
+                    }
+                    if (!found && c == nL) {              // the subset is all there is: the last breakpoint, linesearch.c:148-157
+                        const double dl = D2[i], al = A2[i];
+                        if (dl > 0) { aw = aw + dl * dl; bw = bw - dl * al; } else { aw = aw - dl * dl; bw = bw + dl * al; }
+                        found = true;
+                    }
+                    sm[16] = found ? 1.0 : 0.0; sm[17] = -bw / aw;
+                }
+                SYNC;
+                if (sm[16] != 0.0) { PHL(PH_LS_SORT); return sm[17]; }
+                SYNC;                                     // (sm[16] is read by everyone before the full path may write it again)
+            }
+        }
+    }
+    // stable order by (t, index) of ALL candidates = the reference's qsort
     if (np2 <= SM_THREADS) small_sort_regs<1>(np2, M2, ls_alpha, ls_delta, skey, sidx);
     else if (np2 == 2 * SM_THREADS) small_sort_regs<2>(np2, M2, ls_alpha, ls_delta, skey, sidx);
     else small_sort_regs<4>(np2, M2, ls_alpha, ls_delta, skey, sidx);
