@@ -1168,7 +1168,7 @@ __device__ __forceinline__ void small_solve_body(SmallQP *probs, int count, cons
            *res_prim_old = V[MV_RPOLD], *res_prim_in = V[MV_RPI], *dy = V[MV_DY], *Adx = V[MV_ADX], *dw = V[MV_DW], *E = V[MV_E],
            *Einv = V[MV_EINV], *ats = V[MV_ATS], *tm = V[MV_T], *dwf = V[MV_DWF];
     int *active = P.iv, *active_old = P.iv + m, *changed = P.iv + 2 * m;
-    double *xs = dyn, *colbuf = dyn + n, *tk = dyn + 2 * (size_t)n, *gbuf = dyn + 16 * (size_t)n;     // dyn .. dyn + 16n: l and l*d of four columns during a factorization, two buffers (look-ahead)
+    double *xs = dyn, *colbuf = dyn + n, *tk = dyn + 2 * (size_t)n, *gbuf = dyn + (LAT ? 16 : 8) * (size_t)n;   // dyn .. dyn + 8n: l and l*d of four columns during a factorization; the latency kernel: two such buffers (look-ahead)
     double *d_s = gbuf + (((size_t)(n > m ? n : m) / 4 + 4 + 1) & ~(size_t)1);
     int *rp_s = (int *)(d_s + m);
     double *Klds = (double *)(rp_s + (((size_t)m + 1 + 3) & ~(size_t)3));          // start of U
@@ -1676,8 +1676,8 @@ static int pinned_reserve(char **buf, size_t *cap, size_t need) {
 // NULL sizes the K-in-global-memory layout.
 static const size_t SMALL_LDS_BUDGET = 160 * 1024 - 1024;                // static LDS: reduction scratch only
 static const bool SMALL_BATCH_LAT_DEFAULT = false;                       // (see slot_submit)
-static size_t small_lds_bytes(size_t nmax, size_t mmax, int *klds_ok, size_t *union_bytes = nullptr) {
-    size_t lds = 16 * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
+static size_t small_lds_bytes(size_t nmax, size_t mmax, int *klds_ok, size_t *union_bytes = nullptr, bool lat = false) {
+    size_t lds = (lat ? 16 : 8) * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
     const size_t kbytes = nmax * (nmax + 1) / 2 * 8;
     size_t np2 = 1; while (np2 < 2 * mmax) np2 <<= 1;
     size_t lsbytes = 2 * mmax * (8 + 8) + np2 * (8 + 4) + ((2 * mmax + 15) & ~(size_t)15);   // delta, alpha, keys, indices, flags
@@ -1788,16 +1788,18 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
         int klds_ok = 0; size_t ubytes = 0;
         size_t lds = small_lds_bytes(nmax, mmax, &klds_ok, &ubytes);
         if (const char *kg = getenv("QPDO_SMALL_K_GLOBAL")) { if (atoi(kg) && klds_ok) { klds_ok = 0; lds = small_lds_bytes(nmax, mmax, nullptr, &ubytes); } }      // occupancy experiments
+        int klds_lat = 0; size_t ub_lat = 0;
+        const size_t lds_lat = small_lds_bytes(nmax, mmax, &klds_lat, &ub_lat, true);           // the latency kernel's layout (two factor buffers)
         SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(budget)));
         if (const char *pad = getenv("QPDO_SMALL_LDS_MIN")) { const size_t v = (size_t)atol(pad); if (v > lds && v <= budget) lds = v; }   // occupancy experiments
         const int kflags = klds_ok | ((int)(ubytes / 8) << 1);       // (the LDS_MIN padding experiment below the launch only grows the tail)
         // Which kernel (QPDO_SMALL_BATCH_KERNEL=wide|lat overrides).  "lat": the latency variant -- one workgroup per CU with 256 VGPRs and
         // the item's ~30 work vectors in LDS beside the factor -- whenever everything fits; "wide": two workgroups per CU at 128 VGPRs, vectors
         // in global memory.  Same operations on the same values either way.
-        const size_t voff = (lds + 15) & ~(size_t)15;
+        const size_t voff = (lds_lat + 15) & ~(size_t)15;
         const size_t vbytes = ((size_t)NV_COUNT * nmax + (size_t)MV_COUNT * mmax) * 8 + 3 * mmax * 4 + 16;
         const char *bk = getenv("QPDO_SMALL_BATCH_KERNEL");
-        const bool lat_fits = klds_ok && voff + vbytes <= budget;
+        const bool lat_fits = klds_ok && klds_lat && ub_lat == ubytes && voff + vbytes <= budget;
         const bool use_lat = lat_fits && !(bk && !strcmp(bk, "wide")) && (bk ? !strcmp(bk, "lat") : SMALL_BATCH_LAT_DEFAULT);
         if (use_lat) {
             for (long i = 0; i < count; i++) hp[(size_t)i].batch_vec_off = (unsigned)voff;
@@ -1952,7 +1954,7 @@ struct SmallResident {
 int qdev_small_resident_fits(int32_t n, int32_t m) {
     if (n < 1 || n > SM_MAX_N || m < 0 || m > SM_MAX_M) return 0;
     int ok = 0;
-    (void)small_lds_bytes((size_t)n, (size_t)m, &ok);
+    (void)small_lds_bytes((size_t)n, (size_t)m, &ok, nullptr, true);
     return ok;                                          // the packed factor must live in LDS: beyond that one workgroup is the wrong shape
 }
 void qdev_small_resident_destroy(void *h) {
@@ -1989,7 +1991,7 @@ void *qdev_small_resident_create(const QdevSmallView *v, long trace_cap) {
     SHIP(hipHostMalloc((void **)&R->htrace, (size_t)trace_cap * sizeof(QPDOAmdTraceRec), hipHostMallocDefault));
     R->trace_cap = trace_cap;
     SHIP(hipEventCreate(&R->ev0)); SHIP(hipEventCreate(&R->ev1));
-    { size_t ub = 0; R->lds = small_lds_bytes(n, m, &R->klds_ok, &ub); R->kflags = R->klds_ok | ((int)(ub / 8) << 1); }
+    { size_t ub = 0; R->lds = small_lds_bytes(n, m, &R->klds_ok, &ub, true); R->kflags = R->klds_ok | ((int)(ub / 8) << 1); }
     {   // vectors into LDS when they fit beside everything else (QPDO_SMALL_VEC_LDS=0: keep them in global memory)
         const size_t off = (R->lds + 15) & ~(size_t)15;
         const size_t vbytes = ((size_t)NV_COUNT * n + (size_t)MV_COUNT * m) * 8 + 3 * m * 4 + 16;

@@ -178,11 +178,12 @@ def test_batch_stream_api_edges(gpu_required, capfd):
     capfd.readouterr()
 
 
-@pytest.mark.parametrize("n,m,dens,neq", [(60, 700, 0.1, 50), (100, 1000, 0.05, 0), (30, 1024, 0.2, 10), (250, 513, 0.03, 100), (40, 257, 0.2, 0), (8, 129, 0.5, 2)])
+@pytest.mark.parametrize("n,m,dens,neq", [(60, 700, 0.1, 50), (100, 1000, 0.05, 0), (30, 1024, 0.2, 10), (250, 513, 0.03, 100), (40, 257, 0.2, 0), (8, 129, 0.5, 2), (700, 300, 0.01, 20), (1024, 64, 0.01, 0)])
 def test_fused_batch_is_bit_identical_at_the_breakpoint_counts_that_change_the_sort_layout(n, m, dens, neq, gpu_required):
     """The breakpoint sort of the fused kernel holds 1, 2 or 4 elements per thread (2m <= 512, <= 1024, <= 2048) and its one-lane sums are
     folded by a wave 64 elements at a time: instances on both sides of every layout change (the sweep above stays below m = 320), three
-    seeds each, must carry the oracle's bits."""
+    seeds each, must carry the oracle's bits.  The last two: the largest orders the kernel takes (factor in global memory, n up to 1024) --
+    its dynamic LDS must still fit (a layout change in round 4 did not, and the batch quietly took the generic path)."""
     probs = [problems.random_qp(4400 + 7 * k + m, n, m, dens, neq) for k in range(3)]
     res, failed = solver.solve_batch(probs, verbose=0, max_iter=400)
     assert failed == 0
