@@ -417,12 +417,13 @@ class Batch:
             t.outs.append((x, y))
         return t
 
-    def run(self, settings=None, nthreads=16, **kw):
+    def run(self, settings=None, nthreads=16, results=True, **kw):
+        """results=False: skip building the per-item dicts (25 ms for 4096 items); the outputs are in info_view() and outs"""
         if settings is None:
             settings = default_settings(**kw)
         failed = lib().qpdo_amd_solve_batch(len(self.outs), self.items, C.byref(settings), int(nthreads))
         self.kernel_seconds = float(lib().qpdo_amd_batch_kernel_seconds())
-        return self.results(), int(failed)
+        return (self.results() if results else None), int(failed)
 
     def info_view(self):
         """The items' QPDOInfo fields as ONE numpy structured array over the item array itself (no copy, no per-item Python work):
