@@ -1675,7 +1675,6 @@ static int pinned_reserve(char **buf, size_t *cap, size_t need) {
 // else the linesearch scratch alone; the kernel's layout, k_small_solve).  klds_ok (optional out): 1 when K lives in LDS; passing
 // NULL sizes the K-in-global-memory layout.
 static const size_t SMALL_LDS_BUDGET = 160 * 1024 - 1024;                // static LDS: reduction scratch only
-static const bool SMALL_BATCH_LAT_DEFAULT = false;                       // (see slot_submit)
 static size_t small_lds_bytes(size_t nmax, size_t mmax, int *klds_ok, size_t *union_bytes = nullptr, bool lat = false) {
     size_t lds = (lat ? 16 : 8) * nmax * 8 + ((((nmax > mmax ? nmax : mmax) / 4 + 4 + 1) & ~(size_t)1) * 8) + mmax * 8 + (((mmax + 1 + 3) & ~(size_t)3) * 4);
     const size_t kbytes = nmax * (nmax + 1) / 2 * 8;
@@ -1692,7 +1691,7 @@ static volatile double s_last_kernel_s = 0.0;   // (a statistic: written by whic
 //          // HIP-event duration of the last finished k_small_solve launch (bench.py's latency statement)
 
 // pack the batch into the slot's staging buffer, upload, launch, enqueue the downloads: returns without waiting for the GPU
-static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *items, const QPDOSettings *settings) {
+static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *items, const QPDOSettings *settings, bool one_at_a_time) {
     int rc = 0;
     const bool tprof = getenv("QPDO_SMALL_PROF") && !strcmp(getenv("QPDO_SMALL_PROF"), "2");
     auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
@@ -1794,13 +1793,16 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
         if (const char *pad = getenv("QPDO_SMALL_LDS_MIN")) { const size_t v = (size_t)atol(pad); if (v > lds && v <= budget) lds = v; }   // occupancy experiments
         const int kflags = klds_ok | ((int)(ubytes / 8) << 1);       // (the LDS_MIN padding experiment below the launch only grows the tail)
         // Which kernel (QPDO_SMALL_BATCH_KERNEL=wide|lat overrides).  "lat": the latency variant -- one workgroup per CU with 256 VGPRs and
-        // the item's ~30 work vectors in LDS beside the factor -- whenever everything fits; "wide": two workgroups per CU at 128 VGPRs, vectors
-        // in global memory.  Same operations on the same values either way.
+        // the item's ~30 work vectors in LDS beside the factor; "wide": two workgroups per CU at 128 VGPRs, vectors in global memory.  Same
+        // operations on the same values either way.  The wide kernel has the throughput (4096 C3 items at max_iter 300: 0.064 against
+        // 0.087 s), the latency kernel the faster single item (an item that runs all 10000 passes: 0.27 against 0.33 s).  A batch that is
+        // solved one at a time under a large pass limit is as slow as its slowest item: it takes the latency kernel; batches of a STREAM
+        // overlap their stragglers with the next batches' ordinary items: they take the wide kernel.
         const size_t voff = (lds_lat + 15) & ~(size_t)15;
         const size_t vbytes = ((size_t)NV_COUNT * nmax + (size_t)MV_COUNT * mmax) * 8 + 3 * mmax * 4 + 16;
         const char *bk = getenv("QPDO_SMALL_BATCH_KERNEL");
         const bool lat_fits = klds_ok && klds_lat && ub_lat == ubytes && voff + vbytes <= budget;
-        const bool use_lat = lat_fits && !(bk && !strcmp(bk, "wide")) && (bk ? !strcmp(bk, "lat") : SMALL_BATCH_LAT_DEFAULT);
+        const bool use_lat = lat_fits && !(bk && !strcmp(bk, "wide")) && (bk ? !strcmp(bk, "lat") : (one_at_a_time && (count <= 256 || settings->max_iter >= 1000)));
         if (use_lat) {
             for (long i = 0; i < count; i++) hp[(size_t)i].batch_vec_off = (unsigned)voff;
             SHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_solve_lat), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(budget)));
@@ -1895,7 +1897,7 @@ int qdev_small_eligible(long count, const void *items_) {
 // Solve all items with the fused kernel on `device`, one batch at a time.  Returns 0 on success.
 int qdev_small_batch(int device, long count, void *items_, const void *settings_) {
     std::lock_guard<std::mutex> lock(s_slot0_mu);
-    int rc = slot_submit(s_slot0, device, count, (QPDOAmdBatchItem *)items_, (const QPDOSettings *)settings_);
+    int rc = slot_submit(s_slot0, device, count, (QPDOAmdBatchItem *)items_, (const QPDOSettings *)settings_, true);
     if (rc == 0) rc = slot_finish(s_slot0);
     s_slot0.busy = false;
     return rc;
@@ -1917,7 +1919,7 @@ long qdev_small_stream_submit(void *h, long count, void *items_, const void *set
     std::lock_guard<std::mutex> lock(T->mu);
     for (SmallSlot &S : T->slots) {
         if (S.busy) continue;
-        if (slot_submit(S, T->device, count, (QPDOAmdBatchItem *)items_, (const QPDOSettings *)settings_) != 0) { S.busy = false; return -1; }
+        if (slot_submit(S, T->device, count, (QPDOAmdBatchItem *)items_, (const QPDOSettings *)settings_, false) != 0) { S.busy = false; return -1; }
         S.ticket = T->next_ticket++;
         return S.ticket;
     }
