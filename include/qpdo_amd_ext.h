@@ -37,6 +37,9 @@
  *   QPDO_PCG_MAXIT   PCG iteration cap per Newton step (default 100000)
  *   QPDO_SMALL_FUSED "0": never route qpdo_solve through the fused one-launch kernel (default: workspaces with n <= QPDO_SMALL_FUSED_MAX_N
  *                    = 160, m <= 1024 whose packed Newton matrix fits one workgroup's LDS, verbose = 0, no explicit QPDO_LINSOLVE)
+ *   QPDO_SMALL_BATCH_KERNEL  "wide" | "lat": launch shape of a fused batch (qpdo_amd_solve_batch / batch_stream).  Default: a batch solved one at a
+ *                    time takes the latency kernel (one workgroup per CU, work vectors in LDS) when it has <= 256 items or max_iter >= 1000 -- it is
+ *                    as slow as its slowest item --, batches of a stream the wide one (two workgroups per CU: the throughput).  Same bits either way
  *   QPDO_FIX_STATUS_RESET  "1": reset info->status_val at the start of qpdo_solve
  *                    (the reference does not: src/qpdo.c:451-453 vs :200)
  */
