@@ -367,7 +367,7 @@ def test_production_size_matches_oracle_fixture(name, gpu_required, monkeypatch)
     """Production sizes against committed oracle fixtures (tests/golden/big_<name>.npz, written by
     tests/golden/make_golden_big.py with the oracle's direct LDL' = the reference's algorithm, src/qpdo.c:343-449,
     src/newton.c:21-33).  The device runs its DEFAULT solver selection -- no QPDO_* override: dense MFMA LDL' with
-    look-ahead and low-rank updates at C2 (BASELINE.json configs[1], full size), PCG in Schur-complement mode over
+    look-ahead and low-rank updates at C2 (BASELINE.json configs[1], full size; its first passes through PCG), PCG in Schur-complement mode over
     the auto-selected LDS-staged slab kernels above QPDO_DENSE_MAX_N.  Bar: status, iterations, oterations and the
     per-pass kind / n_active / n_enter / n_leave / factor branch IDENTICAL; tau and the four residual norms per pass
     and the final iterates within the stated tolerances; plus the size-independent properties."""
@@ -393,6 +393,8 @@ def test_production_size_matches_oracle_fixture(name, gpu_required, monkeypatch)
         assert r["stats"]["factor_count"] > 0 and r["stats"]["lin_iters"] == 0
     elif dense:
         assert r["stats"]["lowrank_solves"] > 0              # the kept-factor update path took part
+        if p["n"] >= 8192:                                   # default from n = 8192: the first passes through PCG, then the dense factor (QPDO_HYBRID)
+            assert r["stats"]["lin_iters"] > 0 and r["stats"]["factor_count"] > 0
     else:
         assert r["stats"]["schur_passes"] > 0
     # size-independent properties: independently recomputed KKT residuals, agreement with the reported norms, complementarity
