@@ -1616,13 +1616,70 @@ static void sym_full32(const cholmod_sparse *Q, HostCsr32 &o) {            // fu
         }
     }
 }
+// The same three conversions straight into caller-provided arrays (the pinned staging buffer of a batch): no per-item vectors, no second
+// copy.  `next` / the temporaries are per-thread scratch that only grows.
+static void csc_to_csr32_raw(const cholmod_sparse *M, int *rp, int *ci, double *val, std::vector<int> &next) {
+    const long long nr = (long long)M->nrow, nc = (long long)M->ncol, nnz = idx_at(M->p, M->itype, nc);
+    for (long long i = 0; i <= nr; i++) rp[i] = 0;
+    for (long long k = 0; k < nnz; k++) rp[idx_at(M->i, M->itype, k) + 1]++;
+    for (long long i = 0; i < nr; i++) rp[i + 1] += rp[i];
+    if ((long long)next.size() < nr + 1) next.resize((size_t)nr + 1);
+    for (long long i = 0; i < nr; i++) next[(size_t)i] = rp[i];
+    const double *x = (const double *)M->x;
+    for (long long j = 0; j < nc; j++)
+        for (long long k = idx_at(M->p, M->itype, j); k < idx_at(M->p, M->itype, j + 1); k++) { const int s2 = next[(size_t)idx_at(M->i, M->itype, k)]++; ci[s2] = (int)j; val[s2] = x[k]; }
+}
+static void csc_as_csrT32_raw(const cholmod_sparse *M, int *rp, int *ci, double *val) {
+    const long long nc = (long long)M->ncol, nnz = idx_at(M->p, M->itype, nc);
+    for (long long j = 0; j <= nc; j++) rp[j] = (int)idx_at(M->p, M->itype, j);
+    for (long long k = 0; k < nnz; k++) ci[k] = (int)idx_at(M->i, M->itype, k);
+    if (nnz) memcpy(val, M->x, (size_t)nnz * 8);
+}
+static long long sym_full_nnz(const cholmod_sparse *Q) {              // entries of the full symmetric matrix (sym_full32's count)
+    const long long n = (long long)Q->ncol, nnz = idx_at(Q->p, Q->itype, n);
+    const int st = Q->stype;
+    if (st == 0) return nnz;
+    long long c = 0;
+    for (long long j = 0; j < n; j++)
+        for (long long k = idx_at(Q->p, Q->itype, j); k < idx_at(Q->p, Q->itype, j + 1); k++) {
+            const long long i = idx_at(Q->i, Q->itype, k);
+            if (st < 0) c += (i >= j) + (i > j); else c += (i <= j) + (i < j);      // the stored triangle once, its strict part mirrored
+        }
+    return c;
+}
+struct ConvScratch { std::vector<int> next, Rrp, Rci; std::vector<double> Rval; };
+static void sym_full32_raw(const cholmod_sparse *Q, int *rp, int *ci, double *val, ConvScratch &W) {
+    const int st = Q->stype;
+    if (st == 0) { csc_as_csrT32_raw(Q, rp, ci, val); return; }
+    const long long n = (long long)Q->ncol, nnzs = idx_at(Q->p, Q->itype, n);
+    if ((long long)W.Rrp.size() < n + 1) W.Rrp.resize((size_t)n + 1);
+    if ((long long)W.Rci.size() < nnzs + 1) { W.Rci.resize((size_t)nnzs + 1); W.Rval.resize((size_t)nnzs + 1); }
+    csc_to_csr32_raw(Q, W.Rrp.data(), W.Rci.data(), W.Rval.data(), W.next);
+    const int *Rrp = W.Rrp.data(), *Rci = W.Rci.data(); const double *Rval = W.Rval.data();
+    const double *x = (const double *)Q->x;
+    auto keep_csr = [&](long long i, long long j) { return st < 0 ? j <= i : j >= i; };
+    auto keep_mir = [&](long long i, long long j) { return st < 0 ? i > j : i < j; };
+    int s2 = 0;
+    for (long long i = 0; i < n; i++) {                                  // (the rule and the order of sym_full32)
+        rp[i] = s2;
+        const long long b0 = idx_at(Q->p, Q->itype, i), e0 = idx_at(Q->p, Q->itype, i + 1);
+        if (st < 0) {
+            for (int k = Rrp[i]; k < Rrp[i + 1]; k++) if (keep_csr(i, Rci[k])) { ci[s2] = Rci[k]; val[s2] = Rval[k]; s2++; }
+            for (long long k = b0; k < e0; k++) { const long long r = idx_at(Q->i, Q->itype, k); if (keep_mir(r, i)) { ci[s2] = (int)r; val[s2] = x[k]; s2++; } }
+        } else {
+            for (long long k = b0; k < e0; k++) { const long long r = idx_at(Q->i, Q->itype, k); if (keep_mir(r, i)) { ci[s2] = (int)r; val[s2] = x[k]; s2++; } }
+            for (int k = Rrp[i]; k < Rrp[i + 1]; k++) if (keep_csr(i, Rci[k])) { ci[s2] = Rci[k]; val[s2] = Rval[k]; s2++; }
+        }
+    }
+    rp[n] = s2;
+}
 // One in-flight batch owns a SLOT: a stream, a device arena, pinned host staging for the inputs, the outputs and the per-item
 // control structs, and the per-item conversion buffers -- all grow-only and kept between batches (hipMalloc/hipFree of ~0.5 GB
 // cost ~0.1 s per batch; releasing the host buffers another 0.1 s).  qdev_small_batch uses one static slot; a batch STREAM
 // (qdev_small_stream_*) owns `depth` slots, so that batch i+1 is packed, uploaded and started while the slowest workgroups of
 // batch i still run: a launch is as slow as its slowest item (an instance that never reaches eps runs max_iter passes on one
 // workgroup), and with one batch at a time the other CUs idle behind it.
-struct Lay { size_t Arp, Aci, Aval, Trp, Tci, Tval, Qrp, Qci, Qval, q, l, u, x0, y0, nv, mv, lsv, iv, tpos, K, solx, soly, dx, dy; HostCsr32 A, T, Q; };
+struct Lay { size_t Arp, Aci, Aval, Trp, Tci, Tval, Qrp, Qci, Qval, q, l, u, x0, y0, nv, mv, lsv, iv, tpos, K, solx, soly, dx, dy; size_t nnzA, nnzQ; };
 struct SmallSlot {
     int device = -1;
     hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1705,13 +1762,13 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
     std::vector<Lay> &lay = S.lay;
     // device arena: [inputs of all items][outputs of all items][scratch]; only the inputs are uploaded and only the
     // outputs come back.  The per-item conversions and the copies into the staging buffer run on host threads.
-    parallel_items(count, [&](long i) { const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i]; csc_to_csr32(d->A, L.A); csc_as_csrT32(d->A, L.T); sym_full32(d->Q, L.Q); });
+    parallel_items(count, [&](long i) { const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i]; L.nnzA = (size_t)idx_at(d->A->p, d->A->itype, (long long)d->A->ncol); L.nnzQ = (size_t)sym_full_nnz(d->Q); });
     for (long i = 0; i < count; i++) {
         const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
         const size_t n = d->n, m = d->m;
-        L.Arp = reserve((m + 1) * 4); L.Aci = reserve(L.A.ci.size() * 4 + 4); L.Aval = reserve(L.A.val.size() * 8 + 8);
-        L.Trp = reserve((n + 1) * 4); L.Tci = reserve(L.T.ci.size() * 4 + 4); L.Tval = reserve(L.T.val.size() * 8 + 8);
-        L.Qrp = reserve((n + 1) * 4); L.Qci = reserve(L.Q.ci.size() * 4 + 4); L.Qval = reserve(L.Q.val.size() * 8 + 8);
+        L.Arp = reserve((m + 1) * 4); L.Aci = reserve(L.nnzA * 4 + 4); L.Aval = reserve(L.nnzA * 8 + 8);
+        L.Trp = reserve((n + 1) * 4); L.Tci = reserve(L.nnzA * 4 + 4); L.Tval = reserve(L.nnzA * 8 + 8);
+        L.Qrp = reserve((n + 1) * 4); L.Qci = reserve(L.nnzQ * 4 + 4); L.Qval = reserve(L.nnzQ * 8 + 8);
         L.q = reserve(n * 8); L.l = reserve(m * 8 + 8); L.u = reserve(m * 8 + 8);
         L.x0 = items[i].x0 ? reserve(n * 8) : (size_t)-1; L.y0 = items[i].y0 ? reserve(m * 8 + 8) : (size_t)-1;
     }
@@ -1727,7 +1784,7 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
         const QPDOData *d = items[i].data; Lay &L = lay[(size_t)i];
         const size_t n = d->n, m = d->m;
         L.nv = reserve((size_t)NV_COUNT * n * 8); L.mv = reserve((size_t)MV_COUNT * m * 8 + 8); L.lsv = reserve(4 * m * 8 + 8);
-        L.iv = reserve(3 * m * 4 + 4); L.tpos = reserve(L.A.ci.size() * 4 + 4); L.K = reserve(n * n * 8);
+        L.iv = reserve(3 * m * 4 + 4); L.tpos = reserve(L.nnzA * 4 + 4); L.K = reserve(n * n * 8);
     }
     char *harena = nullptr, *dbase = nullptr; SmallQP *hp = nullptr;
     SHIP(hipSetDevice(device));
@@ -1754,10 +1811,23 @@ static int slot_submit(SmallSlot &S, int device, long count, QPDOAmdBatchItem *i
                 const size_t n = d->n, m = d->m;
                 char *h = harena;
                 const size_t reg_end = (i + 1 < count) ? lay[(size_t)i + 1].Arp : upload_bytes;     // this item's input region, padding included
-                memset(h + L.Arp, 0, reg_end - L.Arp);
-                memcpy(h + L.Arp, L.A.rp.data(), (m + 1) * 4); if (!L.A.ci.empty()) { memcpy(h + L.Aci, L.A.ci.data(), L.A.ci.size() * 4); memcpy(h + L.Aval, L.A.val.data(), L.A.val.size() * 8); }
-                memcpy(h + L.Trp, L.T.rp.data(), (n + 1) * 4); if (!L.T.ci.empty()) { memcpy(h + L.Tci, L.T.ci.data(), L.T.ci.size() * 4); memcpy(h + L.Tval, L.T.val.data(), L.T.val.size() * 8); }
-                memcpy(h + L.Qrp, L.Q.rp.data(), (n + 1) * 4); if (!L.Q.ci.empty()) { memcpy(h + L.Qci, L.Q.ci.data(), L.Q.ci.size() * 4); memcpy(h + L.Qval, L.Q.val.data(), L.Q.val.size() * 8); }
+                // conversions straight into the staging buffer; the slack behind every array (4 / 8 bytes + alignment) is zeroed like the
+                // memset of the whole region used to do it
+                static thread_local ConvScratch W;
+                auto tail0 = [&](size_t off, size_t bytes, size_t next_off) { if (next_off > off + bytes) memset(h + off + bytes, 0, next_off - off - bytes); };
+                csc_to_csr32_raw(d->A, (int *)(h + L.Arp), (int *)(h + L.Aci), (double *)(h + L.Aval), W.next);
+                tail0(L.Arp, (m + 1) * 4, L.Aci); tail0(L.Aci, L.nnzA * 4, L.Aval); tail0(L.Aval, L.nnzA * 8, L.Trp);
+                csc_as_csrT32_raw(d->A, (int *)(h + L.Trp), (int *)(h + L.Tci), (double *)(h + L.Tval));
+                tail0(L.Trp, (n + 1) * 4, L.Tci); tail0(L.Tci, L.nnzA * 4, L.Tval); tail0(L.Tval, L.nnzA * 8, L.Qrp);
+                sym_full32_raw(d->Q, (int *)(h + L.Qrp), (int *)(h + L.Qci), (double *)(h + L.Qval), W);
+                tail0(L.Qrp, (n + 1) * 4, L.Qci); tail0(L.Qci, L.nnzQ * 4, L.Qval); tail0(L.Qval, L.nnzQ * 8, L.q);
+                tail0(L.q, n * 8, L.l); tail0(L.l, m * 8, L.u);
+                {   // u, then the optional x0 / y0, up to the end of this item's region
+                    size_t off = L.u, bytes = m * 8;
+                    if (L.x0 != (size_t)-1) { tail0(off, bytes, L.x0); off = L.x0; bytes = n * 8; }
+                    if (L.y0 != (size_t)-1) { tail0(off, bytes, L.y0); off = L.y0; bytes = m * 8; }
+                    tail0(off, bytes, reg_end);
+                }
                 memcpy(h + L.q, d->q, n * 8); if (m) { memcpy(h + L.l, d->l, m * 8); memcpy(h + L.u, d->u, m * 8); }
                 if (items[i].x0) memcpy(h + L.x0, items[i].x0, n * 8);
                 if (items[i].y0 && m) memcpy(h + L.y0, items[i].y0, m * 8);

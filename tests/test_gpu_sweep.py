@@ -122,6 +122,33 @@ def test_fused_batch_sweep_is_bit_identical(kernel, gpu_required, monkeypatch):
     assert not bad, bad
 
 
+def test_fused_batch_takes_q_in_lower_upper_or_full_storage(gpu_required):
+    """qpdo_amd_solve_batch converts every item's CSC matrices into the kernel's CSR images straight into its staging buffer: Q stored as
+    its lower triangle (stype -1, what the reference's mex passes), its upper triangle (+1) or in full (0) must give the same image, i.e.
+    the same bits out of the kernel"""
+    import scipy.sparse as sp
+    base = [_instance(i)[0] for i in range(12)]
+    def variant(p, st):
+        q = dict(p)
+        L = sp.csc_matrix(sp.tril(p["Q"]))
+        if st == -1: q["Q"] = L
+        elif st == 1: q["Q"] = sp.csc_matrix(L.T)
+        else:
+            F = (L + sp.tril(L, -1).T).tocsc(); F.sort_indices(); q["Q"] = F
+        q["Qstype"] = st
+        return q
+    out = {}
+    for st in (-1, 1, 0):
+        res, failed = solver.solve_batch([variant(p, st) for p in base], verbose=0, max_iter=300)
+        assert failed == 0
+        out[st] = res
+    for a, b, c in zip(out[-1], out[1], out[0]):
+        for r in (b, c):
+            assert (r["info"]["status_val"], r["info"]["iterations"]) == (a["info"]["status_val"], a["info"]["iterations"])
+            assert np.array_equal(r["x"], a["x"], equal_nan=True) and np.array_equal(r["y"], a["y"], equal_nan=True)
+            assert r["info"]["objective"] == a["info"]["objective"] or (np.isnan(r["info"]["objective"]) and np.isnan(a["info"]["objective"]))
+
+
 def test_fused_batch_degenerate_shapes_are_bit_identical(gpu_required):
     """m = 0 (no constraints), n = 1, a single constraint, a row without entries: the fused kernel's sort layouts, wave folds, quartet
     assembly and one-wave solves at their smallest sizes, against the oracle bit for bit"""
