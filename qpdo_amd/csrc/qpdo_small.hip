@@ -1566,58 +1566,12 @@ __global__ __launch_bounds__(SM_THREADS, 2) void k_small_solve_lat(SmallQP *prob
 static thread_local char s_err[256] = "";
 #define SHIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { snprintf(s_err, sizeof(s_err), "%s: %s", #call, hipGetErrorString(e__)); rc = -1; goto done; } } while (0)
 
-struct HostCsr32 { std::vector<int> rp, ci; std::vector<double> val; };
 static inline long long idx_at(const void *a, int itype, long long k) { return itype == 0 ? (long long)((const int *)a)[k] : (long long)((const long long *)a)[k]; }
-static void csc_to_csr32(const cholmod_sparse *M, HostCsr32 &o) {          // CSR of the matrix itself
-    const long long nr = (long long)M->nrow, nc = (long long)M->ncol, nnz = idx_at(M->p, M->itype, nc);
-    o.rp.assign(nr + 1, 0); o.ci.resize(nnz); o.val.resize(nnz);
-    for (long long k = 0; k < nnz; k++) o.rp[idx_at(M->i, M->itype, k) + 1]++;
-    for (long long i = 0; i < nr; i++) o.rp[i + 1] += o.rp[i];
-    std::vector<int> next(o.rp.begin(), o.rp.end() - 1);
-    const double *x = (const double *)M->x;
-    for (long long j = 0; j < nc; j++)
-        for (long long k = idx_at(M->p, M->itype, j); k < idx_at(M->p, M->itype, j + 1); k++) { const int s = next[idx_at(M->i, M->itype, k)]++; o.ci[s] = (int)j; o.val[s] = x[k]; }
-}
-static void csc_as_csrT32(const cholmod_sparse *M, HostCsr32 &o) {         // CSR of the transpose = the CSC arrays
-    const long long nc = (long long)M->ncol, nnz = idx_at(M->p, M->itype, nc);
-    o.rp.resize(nc + 1); o.ci.resize(nnz); o.val.resize(nnz);
-    for (long long j = 0; j <= nc; j++) o.rp[j] = (int)idx_at(M->p, M->itype, j);
-    for (long long k = 0; k < nnz; k++) o.ci[k] = (int)idx_at(M->i, M->itype, k);
-    if (nnz) memcpy(o.val.data(), M->x, (size_t)nnz * 8);
-}
-static void sym_full32(const cholmod_sparse *Q, HostCsr32 &o) {            // full symmetric CSR, rows column-sorted
-    const int st = Q->stype;
-    if (st == 0) { csc_as_csrT32(Q, o); return; }
-    // row i of the full matrix = (lower stored) CSR row i of the stored triangle [columns <= i] followed by the stored column
-    // i below the diagonal, (upper stored) the stored column i above the diagonal followed by CSR row i [columns >= i];
-    // same rule as the host driver's sym_to_full_csr (qpdo_api.c)
-    const long long n = (long long)Q->ncol;
-    HostCsr32 R; csc_to_csr32(Q, R);
-    const double *x = (const double *)Q->x;
-    o.rp.assign(n + 1, 0);
-    auto keep_csr = [&](long long i, long long j) { return st < 0 ? j <= i : j >= i; };
-    auto keep_mir = [&](long long i, long long j) { return st < 0 ? i > j : i < j; };
-    for (long long i = 0; i < n; i++) {
-        int c = 0;
-        for (int k = R.rp[i]; k < R.rp[i + 1]; k++) c += keep_csr(i, R.ci[k]);
-        for (long long k = idx_at(Q->p, Q->itype, i); k < idx_at(Q->p, Q->itype, i + 1); k++) c += keep_mir(idx_at(Q->i, Q->itype, k), i);
-        o.rp[i + 1] = o.rp[i] + c;
-    }
-    o.ci.resize(o.rp[n]); o.val.resize(o.rp[n]);
-    for (long long i = 0; i < n; i++) {
-        int s2 = o.rp[i];
-        const long long b0 = idx_at(Q->p, Q->itype, i), e0 = idx_at(Q->p, Q->itype, i + 1);
-        if (st < 0) {
-            for (int k = R.rp[i]; k < R.rp[i + 1]; k++) if (keep_csr(i, R.ci[k])) { o.ci[s2] = R.ci[k]; o.val[s2] = R.val[k]; s2++; }
-            for (long long k = b0; k < e0; k++) { const long long r = idx_at(Q->i, Q->itype, k); if (keep_mir(r, i)) { o.ci[s2] = (int)r; o.val[s2] = x[k]; s2++; } }
-        } else {
-            for (long long k = b0; k < e0; k++) { const long long r = idx_at(Q->i, Q->itype, k); if (keep_mir(r, i)) { o.ci[s2] = (int)r; o.val[s2] = x[k]; s2++; } }
-            for (int k = R.rp[i]; k < R.rp[i + 1]; k++) if (keep_csr(i, R.ci[k])) { o.ci[s2] = R.ci[k]; o.val[s2] = R.val[k]; s2++; }
-        }
-    }
-}
-// The same three conversions straight into caller-provided arrays (the pinned staging buffer of a batch): no per-item vectors, no second
-// copy.  `next` / the temporaries are per-thread scratch that only grows.
+// CSC -> the kernel's CSR images (A, A' = the CSC arrays narrowed, the full symmetric Q) straight into caller-provided arrays (the pinned
+// staging buffer of a batch): no per-item vectors, no second copy.  `next` / the temporaries are per-thread scratch that only grows.
+// Row i of the full Q = (lower stored) CSR row i of the stored triangle [columns <= i] followed by the stored column i below the
+// diagonal, (upper stored) the stored column i above the diagonal followed by CSR row i [columns >= i]; same rule as the host driver's
+// sym_to_full_csr (qpdo_api.c).
 static void csc_to_csr32_raw(const cholmod_sparse *M, int *rp, int *ci, double *val, std::vector<int> &next) {
     const long long nr = (long long)M->nrow, nc = (long long)M->ncol, nnz = idx_at(M->p, M->itype, nc);
     for (long long i = 0; i <= nr; i++) rp[i] = 0;
