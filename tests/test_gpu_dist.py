@@ -149,7 +149,7 @@ print(json.dumps(dict(counts=[r["info"][k] == ro["info"][k] for k in ("status_va
 def test_bench_contract_with_two_ranks_on_one_gpu(workload, extra, gpu_required):
     """bench.py for N > 1, as the BARE command `python bench.py --gpus 2 ...` with no launcher environment: the script starts its own two
     ranks (here both land on the one GPU: QPDO_BENCH_SHARE_GPU=1; without it fewer than N visible devices is an error) and relays
-    one JSON line from rank 0 with the whole-job aggregate; C2: independent QPs, each rank cycling through two seeded instances;
+    one JSON line from rank 0 with the whole-job aggregate; C2: independent QPs, every rank the instance of the N = 1 line;
     C3: the batch sharded over the ranks.  (The driver's torch.distributed.run form reaches the same code past the launcher.)"""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload] + extra
     # both ranks share the one GPU, where RCCL cannot form a 2-rank communicator: the row-partitioned extra of the default mode
@@ -163,7 +163,7 @@ def test_bench_contract_with_two_ranks_on_one_gpu(workload, extra, gpu_required)
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["unit"] == "newton_iters/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
     if workload == "C2":
-        assert d["scaling"] == "weak" and d["config"]["instances_per_rank"] == 2 and all(v == 1 for v in d["status_val"])
+        assert d["scaling"] == "weak" and d["config"]["instances_per_rank"] == 1 and not d["config"]["distinct_instances"] and all(v == 1 for v in d["status_val"])
         assert d["newton_passes"] > 2 * 3 * 30               # both ranks' passes are in the aggregate
         # north_star's second multi-GPU mode rides along in the same run: ONE instance, rows of A partitioned over the ranks
         rp = d["other_configs"]["row_partition"]
