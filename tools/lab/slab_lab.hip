@@ -698,6 +698,20 @@ int main() {
     {   // compact-shaped product (k = 73000 active rows): workgroup geometry
         const int kk = 73000; const double nnzk = (double)kk * per_row;
         printf("compact shape k=%d\n", kk);
+        if (getenv("LAB_UNR")) {      // loads in flight per lane against the segment length of the compact products (W 20032: ~200 / ~146 entries per segment)
+            for (int rep = 0; rep < 2; rep++) {
+            run_prod_wg<16, 8, 1024>("k=73000 tpr16 unr8 (production)", kk, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnzk);
+            run_prod_wg<16, 7, 1024>("k=73000 tpr16 unr7", kk, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnzk);
+            run_prod_wg<16, 6, 1024>("k=73000 tpr16 unr6", kk, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnzk);
+            run_prod_wg<16, 10, 1024>("k=73000 tpr16 unr10", kk, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnzk);
+            run_prod_wg<8, 14, 1024>("k=73000 tpr8 unr14", kk, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnzk);
+            run_prod_wg<32, 4, 1024>("k=73000 tpr32 unr4", kk, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnzk);
+            run_prod_wg<16, 8, 1024>("full m tpr16 unr8 (production)", m, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnz);
+            run_prod_wg<16, 7, 1024>("full m tpr16 unr7", m, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnz);
+            run_prod_wg<16, 6, 1024>("full m tpr16 unr6", m, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnz);
+            }
+            return 0;
+        }
         if (getenv("LAB_PF")) {
             for (int rep = 0; rep < 2; rep++) {
             run_prod_wg<16, 8, 1024>("k=73000 production", kk, n, 256, 1, sp, nslabs, ci16, ci, val, x, y, nnzk);
