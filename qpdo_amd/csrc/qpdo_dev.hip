@@ -50,6 +50,7 @@ static int set_err(hipError_t e, const char *what, int line) {
 #include "dev/pcg_kernels.inc"
 #include "dev/linesearch.inc"
 #include "dev/dense_kernels.inc"
+#include "dev/mid_kernels.inc"
 #include "dev/transpose.inc"
 #include "dev/band.inc"
 #include "dev/host_core.inc"
