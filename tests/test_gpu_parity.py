@@ -260,6 +260,7 @@ def test_dense_factor_schedules_leave_the_same_bits(gpu_required, monkeypatch):
     the factorization: every element of K receives the same updates in the same order, so the solve is bit-identical"""
     monkeypatch.setenv("QPDO_LINSOLVE", "dense")
     monkeypatch.setenv("QPDO_DENSE_LOWRANK", "0")
+    monkeypatch.setenv("QPDO_DENSE_MID", "0")          # the multi-launch factorization (since round 5 the fallback of the one-launch kernel)
     p = problems.random_qp(77, 1500, 2600, 0.01, 100)
     base = None
     for var in ({"QPDO_DENSE_LOOKAHEAD": "0"}, {"QPDO_DENSE_LOOKAHEAD": "1"}, {"QPDO_DENSE_LOOKAHEAD": "1", "QPDO_SYRK_SWZ": "0"},
@@ -277,6 +278,34 @@ def test_dense_factor_schedules_leave_the_same_bits(gpu_required, monkeypatch):
         else:
             assert r["info"]["iterations"] == base["info"]["iterations"], var
             assert np.array_equal(r["x"], base["x"]) and np.array_equal(r["y"], base["y"]), var
+
+
+def test_one_launch_factorization_matches_the_multi_launch_one_and_the_oracle(gpu_required, monkeypatch):
+    """k_mid_factor (one resident workgroup per 64 x 64 tile, flag hand-offs, forward solve riding along; the default) against the
+    multi-launch blocked factorization it replaces (QPDO_DENSE_MID=0) and against the oracle: orders with one block, with a padded last
+    block (n mod 64 = 8 and = 40), with more tiles than CUs (n = 1500: 300 workgroups); twice in a row: the same bits"""
+    monkeypatch.setenv("QPDO_LINSOLVE", "dense")
+    monkeypatch.setenv("QPDO_DENSE_LOWRANK", "0")
+    for seed, n, m, dens in ((5, 200, 100, 0.1), (6, 64, 150, 0.2), (7, 360, 500, 0.05), (77, 1500, 2600, 0.01)):
+        p = problems.random_qp(seed, n, m, dens, min(50, m // 4))
+        monkeypatch.setenv("QPDO_DENSE_MID", "0")
+        r0 = solver.solve_problem(p, verbose=0)
+        monkeypatch.delenv("QPDO_DENSE_MID")
+        r1 = solver.solve_problem(p, verbose=0)
+        r2 = solver.solve_problem(p, verbose=0)
+        assert r1["stats"]["chain_fallbacks"] == 0 and r1["stats"]["factor_count"] == r0["stats"]["factor_count"] > 0, (n, m)
+        assert_same_outcome(r1, r0["info"], r0["x"], r0["y"], p)
+        assert [(t["kind"], t["n_active"], t["n_enter"], t["n_leave"], t["factor_branch"]) for t in r1["trace"]] == \
+               [(t["kind"], t["n_active"], t["n_enter"], t["n_leave"], t["factor_branch"]) for t in r0["trace"]], (n, m)
+        assert np.array_equal(r1["x"], r2["x"]) and np.array_equal(r1["y"], r2["y"]), (n, m)
+        o = ob.OracleSolver(p, ob.default_settings())
+        ro = o.solve()
+        assert_same_outcome(r1, ro["info"], ro["x"], ro["y"], p)
+        # tau: 5e-8 here instead of the suite's 1e-8 -- instance (7, 360, 500) has an ill-conditioned stretch (passes 33-36) on which the
+        # multi-launch factorization deviates from the oracle by 6.4e-9 and the one-launch one by 1.5e-8 (tools/mid_dev_probe.py,
+        # profiles/r05_mid_dev_probe.txt: on the other nine instances both stay below 2.5e-9, neither is systematically closer)
+        assert_same_trace(r1["trace"], o.trace(), tau_rtol=5e-8)
+        o.close()
 
 
 def test_dense_lowrank_update_matches_refactoring(gpu_required, monkeypatch):

@@ -19,12 +19,15 @@ static int run(int n) {
     for (int i = n; i < ld; i++) K[i + (size_t)i * ld] = 1.0;
     for (int i = 0; i < n; i++) b[i] = frand(seed);
     // host solve (Cholesky-free LDL' in place on a copy, lower)
-    std::vector<double> A(K), x(b);
+    const bool host_ref = n <= 3000;
+    std::vector<double> A(host_ref ? K : std::vector<double>(1)), x(b);
+    if (host_ref) {
     for (int k = 0; k < ld; k++) { const double d = A[k + (size_t)k * ld]; for (int i = k + 1; i < ld; i++) A[i + (size_t)k * ld] /= d;
         for (int j = k + 1; j < ld; j++) { const double t = A[j + (size_t)k * ld] * d; if (t != 0.0) for (int i = j; i < ld; i++) A[i + (size_t)j * ld] -= A[i + (size_t)k * ld] * t; } }
     for (int k = 0; k < ld; k++) for (int i = k + 1; i < ld; i++) x[i] -= A[i + (size_t)k * ld] * x[k];
     for (int k = 0; k < ld; k++) x[k] /= A[k + (size_t)k * ld];
     for (int k = ld - 1; k >= 0; k--) for (int i = k + 1; i < ld; i++) x[k] -= A[i + (size_t)k * ld] * x[i];
+    }
     double *dK, *dK0, *Dg, *Li, *LiT, *rhs, *z, *y, *xs; unsigned int *flags; Ctrl *ctrl;
     (void)hipMalloc(&dK, (size_t)ld * ld * 8); (void)hipMalloc(&dK0, (size_t)ld * ld * 8); (void)hipMalloc(&Dg, ld * 8); (void)hipMalloc(&Li, (size_t)nb * 4096 * 8); (void)hipMalloc(&LiT, (size_t)nb * 4096 * 8);
     (void)hipMalloc(&rhs, ld * 8); (void)hipMalloc(&z, ld * 8); (void)hipMalloc(&y, ld * 8); (void)hipMalloc(&xs, ld * 8); (void)hipMalloc(&flags, (size_t)(nb + 1) * nb * 4); (void)hipMalloc(&ctrl, sizeof(Ctrl));
@@ -34,7 +37,7 @@ static int run(int n) {
     const int grid = nb * (nb + 1) / 2 + nb;
     unsigned int epoch = 0;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    float ms_tot = 0.f; const int reps = 20;
+    float ms_tot = 0.f; const int reps = n > 3000 ? 5 : 20;
     for (int rep = 0; rep < reps + 2; rep++) {
         (void)hipMemcpy(dK, dK0, (size_t)ld * ld * 8, hipMemcpyDeviceToDevice);
         hipLaunchKernelGGL(k_fill_sentinel, dim3(4), dim3(256), 0, 0, ld, z, xs);
@@ -65,6 +68,7 @@ static int run(int n) {
     std::vector<double> xd(ld); Ctrl hc;
     (void)hipMemcpy(xd.data(), xs, ld * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&hc, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost);
     double e = 0, nx = 0; for (int i = 0; i < n; i++) { e = fmax(e, fabs(xd[i] - x[i])); nx = fmax(nx, fabs(x[i])); }
+    if (!host_ref) e = -1.0;
     // residual of the device solution
     double rmax = 0; for (int i = 0; i < n; i++) { double s = -b[i]; for (int j = 0; j < n; j++) s += K[i + (size_t)j * ld] * xd[j]; rmax = fmax(rmax, fabs(s)); }
     printf("n = %4d (nb = %2d, %3d workgroups): factor + forward + backward %.1f us   max |x - x_host| = %.2e (|x| %.2e)   |K x - b| = %.2e   chain_err %d   %s\n",
