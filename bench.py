@@ -59,7 +59,8 @@ PMC_PROFILE = "r04_pmc_schur_inner_c4.json"     # HBM-traffic counters of the do
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks of the job (default: WORLD_SIZE when a launcher started this process, otherwise 1)")
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--workload", default=os.environ.get("QPDO_BENCH_WORKLOAD", "C4"),
@@ -80,7 +81,11 @@ def parse():
     ap.add_argument("--launch-check", action="store_true",
                     help="rank plumbing only: rendezvous, barrier and the two reductions of the timed region, no GPU work (CPU tests of --gpus N)")
     ap.add_argument("--rows-extra-child", action="store_true", help=argparse.SUPPRESS)    # internal: see row_partition_extra
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.gpus_explicit = a.gpus is not None
+    if a.gpus is None:                                      # left at its default: adopt the launcher's world size
+        a.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    return a
 
 
 def dist_setup(n_gpus):
@@ -336,12 +341,17 @@ def row_partition_extra(a, rank, world, dist):
     The RCCL exchange has never run on more than one rank before the first multi-GPU node sees this code (the build pool has one
     GPU per box), so the measurement runs in a CHILD process per rank (`bench.py --rows-extra-child`, started after this rank has
     released its workspaces; the children rendezvous among themselves on a port rank 0 picks): a child that has not finished
-    within QPDO_BENCH_ROWS_TIMEOUT seconds (default 90) is killed by its pid / process group and reported as an error, while this
+    within QPDO_BENCH_ROWS_TIMEOUT seconds (default 300; the clock covers the child's interpreter start, generation and two setups) is killed by its pid / process group and reported as an error, while this
     process -- which never entered that collective -- prints the main line and leaves through its normal barrier with exit code 0."""
-    limit = float(os.environ.get("QPDO_BENCH_ROWS_TIMEOUT", "90"))
+    limit = float(os.environ.get("QPDO_BENCH_ROWS_TIMEOUT", "300"))
     box = [_free_port() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(box[0]), RANK=str(rank), WORLD_SIZE=str(world),
+    # The children form a process group of their OWN on a fresh port.  Under `python -m torch.distributed.run` every rank carries the
+    # elastic agent's variables (TORCHELASTIC_USE_AGENT_STORE=True makes every rank, rank 0 included, a CLIENT of a store the agent
+    # hosts -- on the fresh port nobody would): they are not inherited, nor is anything else the launcher set for its own rendezvous.
+    drop = ("TORCHELASTIC_", "TORCH_NCCL_", "TORCH_DIST", "GROUP_", "ROLE_", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "OMP_NUM_THREADS")
+    env = {k: v for k, v in os.environ.items() if not k.startswith(drop)}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(box[0]), RANK=str(rank), WORLD_SIZE=str(world),
                LOCAL_RANK=os.environ.get("LOCAL_RANK", str(rank)))
     cmd = [sys.executable, os.path.abspath(__file__), "--rows-extra-child", "--gpus", str(world), "--workload", a.workload]
     t0 = time.time()
@@ -372,7 +382,9 @@ def rows_extra_child(a):
     mode = os.environ.get("QPDO_BENCH_ROWS_BACKEND", "rccl")
     res = dict(workload="%s seed 0, rows of A partitioned over %d ranks, the first %d loop passes of a cold solve (max_iter=%d)" % (a.workload, world, passes, passes),
                backend="RCCL all-reduce on the solver's stream" if mode == "rccl" else "torch.distributed (gloo) on host buffers")
+    t0 = time.time()
     prob = problems.config_qp(a.workload, index=0)
+    t_generate = time.time() - t0
     times = []
     for rep in range(2):
         if solver.dist_config(rank, world, mode=mode) != 0:          # an RCCL unique id is one-shot: a fresh one per workspace
@@ -389,7 +401,7 @@ def rows_extra_child(a):
         stt = s.stats()
         s.delete()
     dt = allreduce(dist, [times[-1]], "max")[0]
-    res.update(seconds=dt, setup_s=t_setup, newton_passes=stt["newton_passes"], newton_iters_per_s=stt["newton_passes"] / dt,
+    res.update(seconds=dt, setup_s=t_setup, generate_s=t_generate, newton_passes=stt["newton_passes"], newton_iters_per_s=stt["newton_passes"] / dt,
                iterations=r["info"]["iterations"], status_val=r["info"]["status_val"], cg_iters=stt["lin_iters"],
                collectives=stt["collectives"], inner_collectives=stt["inner_collectives"], inner_steps=stt["inner_steps"],
                inner_solves=stt["inner_solves"], schur_passes=stt["schur_passes"], scaling="strong")
@@ -478,7 +490,7 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(launch_ranks(a, sys.argv[1:]))             # (nothing above this line loads the library or touches HIP)
     rank, world, dist = dist_setup(a.gpus)
-    if world != max(1, a.gpus):
+    if world != max(1, a.gpus):                             # only an EXPLICIT --gpus can disagree with the launcher (the default adopts WORLD_SIZE)
         if rank == 0:
             sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks: refusing to report an inconsistent n_gpus\n" % (a.gpus, world))
         sys.exit(2)

@@ -92,6 +92,14 @@ typedef struct {
     long   fused_solves;    /* qpdo_solve calls of this workspace that ran as ONE launch of the fused small-problem kernel (then linsolve = 2:
                              * in-LDS natural-order LDL' in the oracle's operation order, factor_count = its factorizations)                  */
     double fused_kernel_s;  /* HIP-event duration of that launch in the last qpdo_solve (0 if it took the generic path)                     */
+    /* round 5 (appended: the members above keep their offsets) */
+    long   pcg_rescues;     /* PCG solves that could not converge where no dense factor is possible (n > 40000 or a row partition) and were rescued */
+    long   pcg_rescue_kinds;/* bit 0: the band direct solver took over (banded Newton matrix); bit 1: the pass was redone by plain Jacobi-PCG
+                             * (Schur mode and deflation off, four times the iteration cap)                                                */
+    long   hybrid_pcg_passes;/* hybrid PCG -> dense (default from n = 8192): Newton passes solved by PCG before the dense factor took over --
+                             * `linsolve` reads 1 for such a workspace although its first passes ran PCG                                    */
+    long   band_fallbacks;  /* band factorizations that met a non-positive or non-finite pivot and were redone by the dense solver / PCG   */
+    long   onelaunch_factors;/* dense factorizations that ran as ONE launch of the tile-dataflow kernel (k_mid_factor, the default)          */
 } QPDOAmdStats;
 
 int  qpdo_amd_device_count(void);

@@ -979,6 +979,9 @@ int qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out) {
     out->inner_steps = (long)st.inner_steps; out->inner_collectives = (long)st.inner_collectives;
     out->pcg_max_relres = st.pcg_max_relres;
     out->pcg_dense_fallbacks = (long)st.pcg_dense_fallbacks;
+    out->pcg_rescues = (long)st.pcg_rescues; out->pcg_rescue_kinds = (long)st.pcg_rescue_kinds;
+    out->hybrid_pcg_passes = (long)st.hybrid_pcg_passes; out->band_fallbacks = (long)st.band_fallbacks;
+    out->onelaunch_factors = (long)st.onelaunch_factors;
     out->fused_solves = work->chol->fused_solves;
     out->fused_kernel_s = work->chol->last_fused ? work->chol->fused_kernel_s : 0.0;
     if (work->chol->last_fused) { out->factor_count = work->chol->fused_factor_count; out->linsolve = 2; }

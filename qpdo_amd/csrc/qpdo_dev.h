@@ -54,6 +54,11 @@ typedef struct {
     int64_t chain_fallbacks;    /* dense solves redone stepwise after a polled triangular solve lost a producer */
     double  pcg_max_relres;     /* largest relative residual ||r|| / ||rhs|| any PCG solve of the last qpdo_solve ended with   */
     int64_t pcg_dense_fallbacks;/* PCG solves that did not converge and were redone by the dense solver */
+    int64_t pcg_rescues;        /* PCG solves that did not converge where no dense factor is possible (n > 40000, row partition) and a rescue succeeded */
+    int64_t pcg_rescue_kinds;   /* which: bit 0 band direct solver took over, bit 1 plain Jacobi retry (Schur mode / deflation off, 4x the cap) */
+    int64_t hybrid_pcg_passes;  /* hybrid PCG -> dense: Newton passes that were solved by PCG before the dense factor took over */
+    int64_t band_fallbacks;     /* band factorizations that met a non-positive / non-finite pivot and were redone by another solver */
+    int64_t onelaunch_factors;  /* dense factorizations through the one-launch tile-dataflow kernel (k_mid_factor) */
 } QdevStats;
 
 int qdev_device_count(void);

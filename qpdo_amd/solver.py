@@ -94,7 +94,9 @@ class Stats(C.Structure):
                 ("schur_passes", C.c_long), ("lowrank_solves", C.c_long), ("lowrank_cols", C.c_long), ("lowrank_sweeps", C.c_long),
                 ("lowrank_rejects", C.c_long), ("pcg_soft_accepts", C.c_long), ("collectives", C.c_long), ("inner_solves", C.c_long),
                 ("inner_steps", C.c_long), ("inner_collectives", C.c_long), ("chain_fallbacks", C.c_long),
-                ("pcg_max_relres", C.c_double), ("pcg_dense_fallbacks", C.c_long), ("fused_solves", C.c_long), ("fused_kernel_s", C.c_double)]
+                ("pcg_max_relres", C.c_double), ("pcg_dense_fallbacks", C.c_long), ("fused_solves", C.c_long), ("fused_kernel_s", C.c_double),
+                ("pcg_rescues", C.c_long), ("pcg_rescue_kinds", C.c_long), ("hybrid_pcg_passes", C.c_long), ("band_fallbacks", C.c_long),
+                ("onelaunch_factors", C.c_long)]
 
 
 API_SYMBOLS = ["qpdo_set_default_settings", "qpdo_setup", "qpdo_warm_start", "qpdo_solve", "qpdo_update_settings",

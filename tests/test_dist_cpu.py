@@ -94,3 +94,19 @@ def test_bench_rank_count_must_match_gpus_flag():
     env = dict(_bare_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode != 0 and "refusing" in out.stderr
+
+
+def test_bench_adopts_the_launchers_world_size_when_gpus_is_left_at_its_default():
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py` WITHOUT --gpus reports n_gpus = 2 (the default adopts
+    WORLD_SIZE); only an explicit --gpus that disagrees with the launcher is an error (the test above)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--workload", "C1", "--steps", "2", "--launch-check"]
+    out = subprocess.run(cmd, env=_bare_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["sum_of_rank_plus_one"] == 3.0

@@ -144,6 +144,29 @@ print(json.dumps(dict(counts=[r["info"][k] == ro["info"][k] for k in ("status_va
     assert r["second"] == "refused"
 
 
+def test_bench_under_torch_distributed_run_with_two_ranks_on_one_gpu(gpu_required):
+    """the DRIVER's form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus 2 ...` (static rendezvous: every rank carries TORCHELASTIC_USE_AGENT_STORE and friends).  The row-partition extra starts
+    child processes that rendezvous among themselves; they must not inherit the elastic agent's variables (round 4: they did, every
+    child became a client of a store nobody hosted, and the extra always ended in its timeout)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "QPDO_DEVICE")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=dict(env, QPDO_BENCH_ROWS_BACKEND="host", QPDO_BENCH_ROWS_PASSES="8", QPDO_BENCH_SHARE_GPU="1", QPDO_DEVICE="0"))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    rp = d["other_configs"]["row_partition"]
+    assert "error" not in rp, rp
+    assert rp["iterations"] == 8 and rp["collectives"] > 0
+
+
 @pytest.mark.parametrize("workload,extra", [("C2", ["--steps", "3", "--warmup", "1", "--no-cpu-baseline"]),
                                             ("C3", ["--steps", "2", "--warmup", "1", "--max-iter", "300", "--batch-count", "512", "--no-cpu-baseline"])])
 def test_bench_contract_with_two_ranks_on_one_gpu(workload, extra, gpu_required):
