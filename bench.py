@@ -54,7 +54,7 @@ os.environ["QPDO_FIX_STATUS_RESET"] = "1"
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
 C3_COUNT = 4096           # BASELINE.json configs[2]
 MFMA_PROFILE = "r02_c2_dense_mfma_util_wide.json"   # (re-collected whenever k_ldl_syrk changes; unchanged since round 2)
-PMC_PROFILE = "r04_pmc_schur_inner_c4.json"     # HBM-traffic counters of the dominant kernel (tools/profile_round.sh writes it)
+PMC_PROFILE = "r05_pmc_schur_inner_c4.json"     # HBM-traffic counters of the dominant kernel (tools/profile_round.sh writes it)
 
 
 def parse():
@@ -150,14 +150,14 @@ def host_cores():
     return aff if aff <= 64 else 16
 
 
-def cpu_baseline_single(prob, seconds, mode):
+def cpu_baseline_single(prob, seconds, mode, threads=None):
     """One QP, cold start, reference default settings, all cores (OpenMP in the oracle's products / factor).
     mode 'direct': the reference's own algorithm (natural-order LDL' of Q + sigma I + A'DA, cholmod_interface.c:35-52);
     mode 'pcg': Jacobi-PCG on the same operator, for sizes where the dense factor does not exist (C4: 80 GB).
     The sample is the first `seconds` of the solve; value = Newton passes COMPLETED in it / the time at which the
     last of them ended (early passes have the fewest active rows, so this flatters the CPU)."""
     from oracle import binding as ob
-    cores = host_cores()
+    cores = host_cores() if threads is None else int(threads)
     ob.set_threads(cores)
     t0 = time.time()
     o = ob.OracleSolver(prob, ob.default_settings(), linsolve="dense" if mode == "direct" else "pcg", pcg_tol=1e-12)
@@ -176,11 +176,30 @@ def cpu_baseline_single(prob, seconds, mode):
             else "Jacobi-PCG on the matrix-free Newton operator, OpenMP products (the reference's direct CHOLMOD path would need "
                  "an ~80 GB / 3.3e14-flop factor at this size)")
     return dict(value=(len(done) / t_last) if done else None, unit="newton_iters/s", cores=cores, kind="port",
-                sample=("first %.1f s of a cold-start solve of the same instance with the oracle (%s), default settings, %d threads: "
+                sample=("first %.1f s of a cold-start solve of the same instance with the oracle (%s), default settings, %d thread(s): "
                         "%d Newton passes completed by t=%.1f s%s; oracle setup %.1f s not included"
                         % (dt, what, cores, len(done), t_last, ("" if mode == "direct" else ", %d CG iterations (%.2f it/s)" % (cg, cg / dt)), t_setup)),
                 newton_passes=len(done), seconds=t_last, solved_within_sample=bool(finished),
                 **({} if mode == "direct" else dict(cg_iters_per_s=cg / dt if dt > 0 else None)))
+
+
+def cpu_baseline_small(prob, threads, reps, **settings):
+    """A QP the oracle solves in milliseconds (C1): setup + cold solve, `reps` times, the mean -- what the reference's info->run_time
+    covers (src/qpdo.c:461-464)."""
+    from oracle import binding as ob
+    ob.set_threads(threads)
+    ts = []
+    for _ in range(reps):
+        t0 = time.time()
+        o = ob.OracleSolver(prob, ob.default_settings(**settings))
+        o.solve()
+        ts.append(time.time() - t0)
+        info = o.info()
+        o.close()
+    sec = sum(ts) / len(ts)
+    return dict(value=info["newton_passes"] / sec, unit="newton_iters/s", cores=int(threads), kind="port", seconds_per_solve=sec, best_seconds=min(ts),
+                iterations=info["iterations"], status_val=info["status_val"],
+                sample="setup + cold solve of the same instance by the oracle (dense natural-order LDL'), %d thread%s, mean of %d" % (threads, "" if threads == 1 else "s", reps))
 
 
 def cpu_baseline_batch(probs, seconds, settings_over):
@@ -317,6 +336,26 @@ def small_kernel_roofline(newton_passes, seconds, n_gpus):
                 steps_per_newton_pass=steps, ms_per_newton_pass_per_workgroup=ns_per_step * steps * 1e-6,
                 lds_bandwidth_frac=(newton_passes * lds_bytes / seconds / 1e9) / lds_peak,
                 note="latency-bound; HBM traffic is the problem data once, LDS bandwidth use is a few percent")
+
+
+MFMA_PROFILE = "r05_c2_mid_factor_mfma_util.json"     # SQ_VALU_MFMA_BUSY_CYCLES of the dense factorization kernel (tools/profile_round.sh writes it)
+
+
+def dense_roofline(n, t_f, chk, factor_count, onelaunch, load_profile):
+    """fp64-MFMA roofline entry of the dense LDL' factorization: n^3 / 3 flops over the HIP-event time of one factorization (the
+    workspace's final weights, timed back to back on the solver's stream).  The MFMA-busy share comes from the committed counter
+    profile of this round's build when it is there."""
+    tf = n ** 3 / 3.0 / t_f / 1e12
+    roof = dict(bound="mfma", kernel=("k_mid_factor: the whole LDL' in one launch, one resident workgroup per 64 x 64 tile, v_mfma_f64_16x16x4_f64 products, "
+                                      "flag hand-offs" if onelaunch else "dense LDL' factorization (k_ldl_syrk fp64 MFMA trailing update + diag / panel chain)"),
+                achieved=tf, peak=78.6, unit="TFLOP/s", frac=tf / 78.6, traffic=None, factor_seconds=t_f, flops_per_factor=n ** 3 / 3.0,
+                factor_count=factor_count, onelaunch_factors=onelaunch, solve_residual_check=chk,
+                note="n^3/3 flops over the HIP-event time of one factorization")
+    prof = load_profile(MFMA_PROFILE)
+    if prof is not None:
+        roof["mfma_busy"] = prof
+        roof["mfma_busy_source"] = "profiles/%s (SQ_VALU_MFMA_BUSY_CYCLES over SQ_BUSY_CU_CYCLES-equivalent of the factorization kernel, collected at commit %s)" % (MFMA_PROFILE, prof.get("commit"))
+    return roof
 
 
 def _free_port():
@@ -615,10 +654,7 @@ def main():
         fc = s.stats()["factor_count"]
         t_f, chk = s.bench_dense_factor(reps=5)           # HIP events on the solver's stream, the factor of the final pass's weights
         tf = cfg["n"] ** 3 / 3.0 / t_f / 1e12
-        roof = dict(bound="mfma", kernel="dense LDL' factorization (k_ldl_syrk fp64 MFMA trailing update + diag / panel chain)", achieved=tf, peak=78.6,
-                    unit="TFLOP/s", frac=tf / 78.6, traffic=None, factor_seconds=t_f, flops_per_factor=cfg["n"] ** 3 / 3.0, factor_count=fc,
-                    solve_residual_check=chk, note="n^3/3 flops over the HIP-event time of one factorization; MFMA-busy share of k_ldl_syrk in "
-                                                   "profiles/r01_c2_dense_mfma_util.json (35.5 % of 1024 SIMDs)")
+        roof = dense_roofline(cfg["n"], t_f, chk, fc, s.stats().get("onelaunch_factors", 0), load_profile)
     elif ac_n > at_n and ac_time > 0:
         bench_t, full_bytes = s.bench_spmv(0, reps=20)
         achieved = ac_bytes / ac_time / 1e9
@@ -632,7 +668,7 @@ def main():
             pin = load_profile(PMC_PROFILE)
             used_profile = PMC_PROFILE
             if pin is None:                                      # (this round's collection not committed yet: the previous round's, under the same geometry check)
-                used_profile = PMC_PROFILE.replace("r04_", "r03_")
+                used_profile = PMC_PROFILE.replace("r05_", "r04_")
                 pin = load_profile(used_profile)
             ent = pin.get("k_spmv_slab<EpiSchurW>") if pin is not None else None
             live = ac_bytes / ac_n
@@ -708,6 +744,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline_single(prob, a.cpu_seconds, "direct" if cfg["n"] <= 20000 else "pcg")
         except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU line
             out["cpu_baseline"] = dict(value=None, unit="newton_iters/s", cores=host_cores(), kind="port", sample="failed: %r" % (e,))
+        # the reference is single-threaded (src/qpdo.c has no threading; its only clock is util.c:245-264): the same sample on ONE thread
+        try:
+            one = cpu_baseline_single(prob, min(a.cpu_seconds, 15.0), "direct" if cfg["n"] <= 20000 else "pcg", threads=1)
+            out["cpu_baseline"]["single_thread"] = {k: one.get(k) for k in ("value", "unit", "cores", "kind", "sample", "newton_passes", "seconds", "cg_iters_per_s") if k in one}
+        except Exception as e:
+            out["cpu_baseline"]["single_thread"] = dict(value=None, cores=1, sample="failed: %r" % (e,))
         if a.workload == "C4":
             # The sample above is the first ~25 s of the oracle's solve: its cheapest passes.  The WHOLE solve of this instance by the
             # oracle is on record (tests/golden/big_C4_full.npz, written by tests/golden/make_golden_big.py on the build container;
@@ -747,6 +789,34 @@ def main():
         # same process (configs[1]: one QP n=1e4, m=2e4; configs[2]: 4096 MPC-sized QPs through the fused batch kernel), each
         # with its own measured CPU baseline
         try:
+            # qpdo_setup once more in the same process (the first workspace is gone): what is left of setup_s once the code objects are loaded
+            # and 20 GB of device memory have been touched; host part: CSC marshalling + OpenMP conversions on `host_threads` threads
+            t0 = time.time(); sw = solver.QPDO().setup(prob["Q"], prob["q"], prob["A"], prob["l"], prob["u"], Qstype=-1, **st); out["setup_s_second_workspace"] = time.time() - t0
+            sw.delete()
+            out["host_threads"] = host_cores()
+        except Exception as e:
+            out["setup_s_second_workspace"] = None
+        try:
+            # BASELINE.json configs[0]: examples/demo_mex.m's shape (n = 200, m = 100, density 0.1), seeded generator, max_iter = 200 as in the demo
+            pc1 = problems.config_qp("C1")
+            sc1 = solver.QPDO().setup(pc1["Q"], pc1["q"], pc1["A"], pc1["l"], pc1["u"], Qstype=-1, verbose=0, max_iter=200)
+            best1 = None
+            for _ in range(5):
+                t0 = time.time(); rc1 = sc1.solve(); d1 = time.time() - t0
+                best1 = d1 if best1 is None or d1 < best1 else best1
+            stc1 = sc1.stats()
+            sc1.delete()
+            c1 = dict(workload="n=200, m=100, density 0.1 (examples/demo_mex.m:7-9), cold start, default settings + max_iter=200", cold_solve_ms=1e3 * best1,
+                      iterations=rc1["info"]["iterations"], oterations=rc1["info"]["oterations"], status_val=rc1["info"]["status_val"],
+                      newton_iters_per_s=stc1["newton_passes"] / best1, factor_count=stc1["factor_count"], onelaunch_factors=stc1.get("onelaunch_factors"),
+                      route="fused one-launch kernel" if stc1["linsolve"] == 2 else "generic path, dense LDL' in one launch per factorization")
+            if not a.no_cpu_baseline:
+                c1["cpu_baseline"] = cpu_baseline_small(pc1, host_cores(), 10, max_iter=200)
+                c1["cpu_baseline"]["single_thread"] = cpu_baseline_small(pc1, 1, 10, max_iter=200)
+            out.setdefault("other_configs", {})["C1"] = c1
+        except Exception as e:
+            out.setdefault("other_configs", {})["C1"] = dict(error=repr(e))
+        try:
             p2 = problems.config_qp("C2")
             t0 = time.time(); s3 = solver.QPDO().setup(p2["Q"], p2["q"], p2["A"], p2["l"], p2["u"], Qstype=-1, verbose=0); ts = time.time() - t0
             s3.solve()                                                            # warm-up (code objects, allocations)
@@ -754,14 +824,19 @@ def main():
             st3 = s3.stats()
             t_f3, _ = s3.bench_dense_factor(reps=5) if st3["linsolve"] == 1 else (None, None)
             s3.delete()
-            out["other_configs"] = {"C2": dict(workload="n=10000, m=20000, density 0.01, cold start, default settings", time_to_eps_s=dt3, setup_s=ts,
-                                               roofline=(dict(bound="mfma", kernel="dense LDL' factorization", achieved=1e4 ** 3 / 3 / t_f3 / 1e12, peak=78.6, unit="TFLOP/s",
-                                                              frac=1e4 ** 3 / 3 / t_f3 / 1e12 / 78.6, factor_seconds=t_f3) if t_f3 else None),
+            out.setdefault("other_configs", {})["C2"] = dict(workload="n=10000, m=20000, density 0.01, cold start, default settings", time_to_eps_s=dt3, setup_s=ts,
+                                               roofline=(dense_roofline(10000, t_f3, None, st3["factor_count"], st3.get("onelaunch_factors", 0), load_profile) if t_f3 else None),
+                                               hybrid_pcg_passes=st3.get("hybrid_pcg_passes"),
                                                newton_iters_per_s=st3["newton_passes"] / dt3, status_val=r3["info"]["status_val"],
                                                iterations=r3["info"]["iterations"], linsolve="dense-ldlt" if st3["linsolve"] == 1 else "pcg",
-                                               factor_count=st3["factor_count"], lowrank_solves=st3["lowrank_solves"])}
+                                               factor_count=st3["factor_count"], lowrank_solves=st3["lowrank_solves"])
             if not a.no_cpu_baseline:
                 out["other_configs"]["C2"]["cpu_baseline"] = cpu_baseline_single(p2, 20.0, "direct")
+                try:
+                    one2 = cpu_baseline_single(p2, 12.0, "direct", threads=1)
+                    out["other_configs"]["C2"]["cpu_baseline"]["single_thread"] = {k: one2.get(k) for k in ("value", "unit", "cores", "kind", "sample", "newton_passes", "seconds")}
+                except Exception as e:
+                    out["other_configs"]["C2"]["cpu_baseline"]["single_thread"] = dict(value=None, cores=1, sample="failed: %r" % (e,))
             nb = C3_COUNT
             probs = [problems.config_qp("C3", i) for i in range(nb)]
             B = solver.Batch(probs)

@@ -122,7 +122,7 @@ int  qpdo_amd_spmv(QPDOWorkspace *work, int which, const double *v, double *y);
 int  qpdo_amd_linesearch(QPDOWorkspace *work, double eta, double beta, const double *delta,
                          const double *alpha, double *tau);
 /* copy a device-resident vector to the host: 0 x, 1 Qx, 2 y, 3 mu, 4 d (factor weights),
- * 5 dx, 6 dy, 7 Ax, 8 Aty, 9 l, 10 u */
+ * 5 dx, 6 dy, 7 Ax, 8 Aty, 9 l, 10 u, 11 ybar, 12 xbar, 13 w (of the last loop pass that ran) */
 int  qpdo_amd_download(QPDOWorkspace *work, int which, double *dst);
 
 /* ---- one large QP row-partitioned over G GPUs (BASELINE.json configs[3]) --------------------------------

@@ -109,10 +109,10 @@ def default_settings(**over):
 
 _VEC = dict(sol_x=0, sol_y=1, dx=2, dy=3, x=4, y=5, mu=6, D=7, E=8, q=9, l=10, u=11, Ax_vals=12,
             Qx_vals=13, Qx=14, Ax=15, Aty=16, d=17, Qdx=18, Adx=19, Atdy=20, res_prim_in=21,
-            res_dual_in=22, ls_delta=23, ls_alpha=24)
+            res_dual_in=22, ls_delta=23, ls_alpha=24, xbar=25, ybar=26, w=27)
 _VLEN = dict(sol_x="n", sol_y="m", dx="n", dy="m", x="n", y="m", mu="m", D="n", E="m", q="n", l="m",
              u="m", Qx="n", Ax="m", Aty="n", d="m", Qdx="n", Adx="m", Atdy="n", res_prim_in="m",
-             res_dual_in="n", ls_delta="2m", ls_alpha="2m")
+             res_dual_in="n", ls_delta="2m", ls_alpha="2m", xbar="n", ybar="m", w="m")
 
 
 class OracleSolver:

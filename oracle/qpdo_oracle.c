@@ -1449,6 +1449,7 @@ const f64 *oracle_vec(Oracle *o, int which) {
         case 14: return o->Qx; case 15: return o->Ax; case 16: return o->Aty; case 17: return o->d;
         case 18: return o->Qdx; case 19: return o->Adx; case 20: return o->Atdy;
         case 21: return o->res_prim_in; case 22: return o->res_dual_in; case 23: return o->ls_delta; case 24: return o->ls_alpha;
+        case 25: return o->xbar; case 26: return o->ybar; case 27: return o->w;
     }
     return NULL;
 }

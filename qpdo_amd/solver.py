@@ -345,7 +345,7 @@ class QPDO:
     def download(self, name):
         which, n = {"x": (0, self.n), "Qx": (1, self.n), "y": (2, self.m), "mu": (3, self.m), "d": (4, self.m),
                     "dx": (5, self.n), "dy": (6, self.m), "Ax": (7, self.m), "Aty": (8, self.n),
-                    "l": (9, self.m), "u": (10, self.m)}[name]
+                    "l": (9, self.m), "u": (10, self.m), "ybar": (11, self.m), "xbar": (12, self.n), "w": (13, self.m)}[name]
         out = np.zeros(n)
         lib().qpdo_amd_download(self._w, which, _as_dp(out))
         return out

@@ -93,3 +93,47 @@ def same_trace_counts(got, ref):
     """integer part of the per-pass trace only (pass kind, active-set size, rows entering / leaving, factor branch)"""
     return len(got) == len(ref) and all(
         int(g[f]) == int(r[f]) for g, r in zip(got, ref) for f in ("kind", "n_active", "n_enter", "n_leave", "factor_branch"))
+
+
+# ---- runs that crawl to max_iter (tests/test_gpu_sweep.py) ------------------------------------------------------------------------------
+# A run the oracle itself ends at max_iter (-5) may differ from the device's in the per-pass integers after ~100-250 passes.  Round 4
+# read those as rows sitting exactly on a bound; measured (tools/sweep_knife_edges.py, profiles/r05_sweep_knife_edges.txt: the 10 + 13
+# such runs among 720 instances, dense and PCG) that is true of about half of them (margins min(|w - l|, |u - w|) / max(1, |w|) of 0 to
+# 1e-8 at the first differing pass), while on the others -- inner_max_iter of 2-4 passes, mu_min = 1e-12 or no proximal term -- the two
+# iterates have separated by 1e-2 .. 1e3 by then although every integer of the first 80-260 passes still agreed: the iteration is not
+# contracting there and amplifies rounding differences, and no margin bound explains the eventual flip.  What CAN be asserted for such a
+# run, and is (device_active_count_consistent): at the first pass whose integers differ, the device's own active-set count is the count of
+# rows with w <= l or w >= u in the w the device itself computed for that pass (reference src/newton.c:96-107) -- the device's integers
+# follow from its iterate; an active-set bug cannot hide behind the max_iter exemption.
+
+
+def first_integer_mismatch(got, ref):
+    for k, (g, r) in enumerate(zip(got, ref)):
+        if any(int(g[f]) != int(r[f]) for f in ("kind", "n_active", "n_enter", "n_leave", "factor_branch")):
+            return k
+    return None if len(got) == len(ref) else min(len(got), len(ref))
+
+
+def knife_edge_margins(prob, settings, k):
+    """margins min(|w - l|, |u - w|) / max(1, |w|) of every row in the ORACLE's state entering loop pass k (its first k passes re-run)"""
+    from oracle import binding as ob
+    o = ob.OracleSolver(prob, ob.default_settings(**dict(settings, max_iter=k)))
+    o.solve()
+    # (store_solution leaves y multiplied by 1/c in place, termination.c:85 -- undo it)
+    y = o.vec("y") * (o.info()["scaling_c"] if settings.get("scaling", 10) > 0 else 1.0)
+    w = o.vec("Ax") + o.vec("mu") * (o.vec("ybar") - 0.5 * y)
+    l, u = o.vec("l"), o.vec("u")
+    o.close()
+    return np.minimum(np.abs(w - l), np.abs(u - w)) / np.maximum(1.0, np.abs(w))
+
+
+def device_active_count_consistent(prob, settings, k):
+    """the device's n_active of loop pass k (a Newton pass) against the rows with w <= l or w >= u in the device's own w of that pass
+    (the run is repeated with max_iter = k + 1, so that pass k is the last one that ran and its w is what the workspace holds)"""
+    from qpdo_amd import solver
+    s = solver.QPDO().setup(prob["Q"], prob["q"], prob["A"], prob["l"], prob["u"], Qstype=prob.get("Qstype", -1), verbose=0, **dict(settings, max_iter=k + 1))
+    s.solve()
+    tr = s.trace()
+    w, l, u = s.download("w"), s.download("l"), s.download("u")
+    s.delete()
+    return len(tr) == k + 1 and int(tr[k]["kind"]) == 0 and int(tr[k]["n_active"]) == int(((w <= l) | (w >= u)).sum())

@@ -5,7 +5,7 @@ tolerance.  The instances are cheap for the oracle (n <= 160), so the sweep runs
 import numpy as np
 import pytest
 
-from helpers import close_vec, same_trace_counts
+from helpers import close_vec, device_active_count_consistent, first_integer_mismatch, same_trace_counts
 from oracle import binding as ob
 from qpdo_amd import problems, solver
 
@@ -72,6 +72,13 @@ def test_randomized_sweep_matches_oracle(mode, gpu_required, monkeypatch):
         # 3 of the 120 instances, identically for the dense and both PCG solvers) -- they are compared through their counts
         if oi["status_val"] != -5:
             same = same and same_trace_counts(r["trace"], to)
+        elif same and not same_trace_counts(r["trace"], to):
+            # (round 5) ... but not unconditionally: at the first pass whose integers differ the pass kinds must still agree (a Newton
+            # pass on both sides) and the device's count must follow from the device's own w of that pass (helpers.py: what was measured on
+            # these runs, and why no margin bound is asserted)
+            k = first_integer_mismatch(r["trace"], to)
+            same = k is not None and k < len(to) and k < len(r["trace"]) and int(r["trace"][k]["kind"]) == int(to[k]["kind"]) == 0 \
+                and device_active_count_consistent(p, st, k)
         # a run stopped by max_iter is compared through its counts only (its iterate is mid-flight, not a solution)
         if same and oi["status_val"] not in (-3, -4, -5):
             same = close_vec(r["x"], ox, rtol) and close_vec(r["y"], oy, rtol)
