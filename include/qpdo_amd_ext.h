@@ -15,7 +15,7 @@
  *   QPDO_HYBRID      where the dense solver is selected automatically and n >= 8192, every solve starts with PCG and switches to the dense
  *                    factor at the first Newton pass that needs more than 450 PCG iterations (default since round 4; n = 1e4: 0.473 -> 0.452 s,
  *                    same per-pass integers).  "0": off; "1": on from n = 4096; "<budget>" > 1: on from n = 4096 with that budget
- *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change, "1": low-rank update of the kept dense factor (default: from n = 2560 up)
+ *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change, "1": low-rank update of the kept dense factor (default: from n = 9000 up)
  *   QPDO_DENSE_LOOKAHEAD "0": factor on one stream, "1": overlap the next panel with the trailing update (default: from n = 7000 up)
  *   QPDO_DENSE_RESERVE_CUS  CUs left out of the trailing-update stream's mask (default 32; 0 = no mask)
  *   QPDO_DENSE_SOLVE "steps": per-block-step triangular solve kernels instead of the one-launch chained solves

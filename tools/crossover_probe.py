@@ -6,9 +6,9 @@ for n in ([int(a) for a in sys.argv[1:]] or [1000, 2000, 4000, 6000, 8000, 10000
     p = problems.random_qp(500 + n, n, 2 * n, 0.01, 0)
     out = []
     for mode in ("dense", "pcg"):
-        if mode == "dense" and n > 18000: out.append("-"); continue
+        if mode == "dense" and n > 30000: out.append("-"); continue
         os.environ["QPDO_LINSOLVE"] = mode
-        os.environ["QPDO_DENSE_MAX_N"] = "18000"
+        os.environ["QPDO_DENSE_MAX_N"] = "30000"
         t = time.time(); r = solver.solve_problem(p, verbose=0); dt = time.time() - t
         out.append("%s %.3fs (it %d, %s)" % (mode, r["info"]["solve_time"], r["info"]["iterations"], r["info"]["status"]))
     print(n, " | ".join(out), flush=True)

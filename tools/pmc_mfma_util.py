@@ -1,11 +1,11 @@
 """Aggregate a rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE counter_collection.csv per kernel.
-usage: pmc_mfma_util.py <counter_collection.csv> <out.json> <description>"""
+usage: pmc_mfma_util.py <counter_collection.csv> <out.json> <description> [commit]"""
 import csv, json, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); ndisp = collections.defaultdict(set)
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"].split("(")[0].replace("void ", "")
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); ndisp[k].add(r["Dispatch_Id"])
-out = {"what": sys.argv[3],
+out = {"what": sys.argv[3], "commit": sys.argv[4] if len(sys.argv) > 4 else None,
        "note": "mfma_util = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); GRBM_GUI_ACTIVE is reported summed over the 8 XCDs; counter collection serialises dispatches, so durations here are not the overlapped production timeline",
        "kernels": {}}
 for k, c in agg.items():
