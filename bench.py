@@ -352,9 +352,11 @@ def dense_roofline(n, t_f, chk, factor_count, onelaunch, load_profile):
                 factor_count=factor_count, onelaunch_factors=onelaunch, solve_residual_check=chk,
                 note="n^3/3 flops over the HIP-event time of one factorization")
     prof = load_profile(MFMA_PROFILE)
-    if prof is not None:
-        roof["mfma_busy"] = prof
-        roof["mfma_busy_source"] = "profiles/%s (SQ_VALU_MFMA_BUSY_CYCLES over SQ_BUSY_CU_CYCLES-equivalent of the factorization kernel, collected at commit %s)" % (MFMA_PROFILE, prof.get("commit"))
+    ent = (prof or {}).get("kernels", {}).get("k_mid_factor")
+    if ent is not None and onelaunch:
+        roof["mfma_busy_pct_of_1024_simds"] = ent.get("mfma_util_pct_of_1024_simds")
+        roof["mfma_busy_source"] = ("profiles/%s, collected at commit %s: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) summed over the %s "
+                                    "k_mid_factor dispatches of a C2 bench run in a separate rocprofv3 --pmc pass" % (MFMA_PROFILE, prof.get("commit"), ent.get("dispatches")))
     return roof
 
 

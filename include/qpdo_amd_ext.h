@@ -13,8 +13,11 @@
  *                    n <= 40000 -- its assembly tiles the LDS accumulator, QPDO_DENSE_ASM_TILE rows at a time -- and is also the rescue of
  *                    a PCG solve that cannot converge up to that order)
  *   QPDO_HYBRID      where the dense solver is selected automatically and n >= 8192, every solve starts with PCG and switches to the dense
- *                    factor at the first Newton pass that needs more than 450 PCG iterations (default since round 4; n = 1e4: 0.473 -> 0.452 s,
- *                    same per-pass integers).  "0": off; "1": on from n = 4096; "<budget>" > 1: on from n = 4096 with that budget
+ *                    factor at the first Newton pass that needs more than 450 PCG iterations (default since round 4; same per-pass integers;
+ *                    QPDOAmdStats.hybrid_pcg_passes counts the PCG passes; every numerical PCG failure hands the pass to the dense factor).  "0": off; "1": on from n = 4096; "<budget>" > 1: on from n = 4096 with that budget
+ *   QPDO_DENSE_MID   "0": the dense factorization as the multi-launch blocked pipeline of rounds 1-4 instead of ONE launch of tile-owning
+ *                    workgroups (k_mid_factor, the default at every order since round 5: n = 1e4 8.4 ms against 13.3 ms).  The
+ *                    look-ahead / outer-panel / syrk knobs below act on the multi-launch path only
  *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change, "1": low-rank update of the kept dense factor (default: from n = 9000 up)
  *   QPDO_DENSE_LOOKAHEAD "0": factor on one stream, "1": overlap the next panel with the trailing update (default: from n = 7000 up)
  *   QPDO_DENSE_RESERVE_CUS  CUs left out of the trailing-update stream's mask (default 32; 0 = no mask)
