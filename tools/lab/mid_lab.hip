@@ -49,6 +49,17 @@ static int run(int n) {
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (rep >= 2) ms_tot += ms;
     }
+    // the backward chain alone (sentinel refill + chain per repetition; the refill is a ~2 us launch)
+    float ms_chain = 0.f;
+    {
+        (void)hipEventRecord(e0);
+        for (int rep = 0; rep < reps; rep++) {
+            hipLaunchKernelGGL(k_fill_sentinel, dim3(4), dim3(256), 0, 0, ld, xs, xs);
+            hipLaunchKernelGGL(k_ldl_chain<false>, dim3(1, nb), dim3(256), 0, 0, (const double *)dK, ld, nb, (const double *)LiT, (const double *)Dg, (const double *)y, xs, (double *)nullptr, 0, ctrl);
+        }
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms_chain, e0, e1);
+    }
     hipError_t err = hipDeviceSynchronize();
 #ifdef MID_TIMING
     if (nb <= 5) {
@@ -71,8 +82,8 @@ static int run(int n) {
     if (!host_ref) e = -1.0;
     // residual of the device solution
     double rmax = 0; for (int i = 0; i < n; i++) { double s = -b[i]; for (int j = 0; j < n; j++) s += K[i + (size_t)j * ld] * xd[j]; rmax = fmax(rmax, fabs(s)); }
-    printf("n = %4d (nb = %2d, %3d workgroups): factor + forward + backward %.1f us   max |x - x_host| = %.2e (|x| %.2e)   |K x - b| = %.2e   chain_err %d   %s\n",
-           n, nb, grid, ms_tot * 1e3 / reps, e, nx, rmax, hc.cnt[C_CHAIN_ERR], hipGetErrorString(err));
+    printf("n = %4d (nb = %2d, %3d workgroups): factor + forward + backward %.1f us (refill + backward chain alone %.1f us)   max |x - x_host| = %.2e (|x| %.2e)   |K x - b| = %.2e   chain_err %d   %s\n",
+           n, nb, grid, ms_tot * 1e3 / reps, ms_chain * 1e3 / reps, e, nx, rmax, hc.cnt[C_CHAIN_ERR], hipGetErrorString(err));
     (void)hipFree(dK); (void)hipFree(dK0); (void)hipFree(Dg); (void)hipFree(Li); (void)hipFree(LiT); (void)hipFree(rhs); (void)hipFree(z); (void)hipFree(y); (void)hipFree(xs); (void)hipFree(flags); (void)hipFree(ctrl);
     return 0;
 }
