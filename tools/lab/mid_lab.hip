@@ -28,9 +28,9 @@ static int run(int n) {
     for (int k = 0; k < ld; k++) x[k] /= A[k + (size_t)k * ld];
     for (int k = ld - 1; k >= 0; k--) for (int i = k + 1; i < ld; i++) x[k] -= A[i + (size_t)k * ld] * x[i];
     }
-    double *dK, *dK0, *Dg, *Li, *LiT, *rhs, *z, *y, *xs; unsigned int *flags; Ctrl *ctrl;
+    double *dK, *dK0, *Dg, *Li, *LiT, *rhs, *z, *y, *xs, *Cp, *Dinv; unsigned int *flags; Ctrl *ctrl;
     (void)hipMalloc(&dK, (size_t)ld * ld * 8); (void)hipMalloc(&dK0, (size_t)ld * ld * 8); (void)hipMalloc(&Dg, ld * 8); (void)hipMalloc(&Li, (size_t)nb * 4096 * 8); (void)hipMalloc(&LiT, (size_t)nb * 4096 * 8);
-    (void)hipMalloc(&rhs, ld * 8); (void)hipMalloc(&z, ld * 8); (void)hipMalloc(&y, ld * 8); (void)hipMalloc(&xs, ld * 8); (void)hipMalloc(&flags, (size_t)(nb + 1) * nb * 4); (void)hipMalloc(&ctrl, sizeof(Ctrl));
+    (void)hipMalloc(&Cp, (size_t)nb * 4096 * 8); (void)hipMalloc(&Dinv, ld * 8); (void)hipMalloc(&rhs, ld * 8); (void)hipMalloc(&z, ld * 8); (void)hipMalloc(&y, ld * 8); (void)hipMalloc(&xs, ld * 8); (void)hipMalloc(&flags, (size_t)(nb + 1) * nb * 4); (void)hipMalloc(&ctrl, sizeof(Ctrl));
     (void)hipMemset(flags, 0, (size_t)(nb + 1) * nb * 4); (void)hipMemset(ctrl, 0, sizeof(Ctrl));
     (void)hipMemcpy(dK0, K.data(), (size_t)ld * ld * 8, hipMemcpyHostToDevice); (void)hipMemcpy(rhs, b.data(), ld * 8, hipMemcpyHostToDevice);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mid_factor), hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS_DOUBLES * 8);
@@ -43,7 +43,7 @@ static int run(int n) {
         hipLaunchKernelGGL(k_fill_sentinel, dim3(4), dim3(256), 0, 0, ld, z, xs);
         (void)hipDeviceSynchronize();
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL(k_mid_factor, dim3(grid), dim3(256), MID_LDS_DOUBLES * 8, 0, dK, n, ld, nb, Dg, Li, LiT, (const double *)rhs, z, y, flags, ++epoch, ctrl);
+        hipLaunchKernelGGL(k_mid_factor, dim3(grid), dim3(256), MID_LDS_DOUBLES * 8, 0, dK, n, ld, nb, Dg, Li, LiT, (const double *)rhs, z, y, flags, ++epoch, ctrl, Cp, Dinv);
         hipLaunchKernelGGL(k_ldl_chain<false>, dim3(1, nb), dim3(256), 0, 0, (const double *)dK, ld, nb, (const double *)LiT, (const double *)Dg, (const double *)y, xs, (double *)nullptr, 0, ctrl);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
