@@ -308,6 +308,24 @@ def test_one_launch_factorization_matches_the_multi_launch_one_and_the_oracle(gp
         o.close()
 
 
+def test_control_block_read_back_by_publication_is_the_copy_path_bit_for_bit(gpu_required, monkeypatch):
+    """The per-pass read-back (dev/host_core.inc read_ctrl_block): a one-wave kernel writes the control block and a sequence word into
+    coherent pinned memory while the host spins (default) against hipMemcpyAsync + hipStreamSynchronize (QPDO_CTRL_PUBLISH=0).  Only the
+    transport differs, so every route gives the same bits: dense one-launch (C1), PCG with its inner control block (Schur mode), and a
+    mid-size dense instance whose factorizations outlast the bounded spin (the hand-over to hipStreamSynchronize)."""
+    cases = [("dense", problems.config_qp("C1")), ("pcg", problems.random_qp(11, 900, 1500, 0.02, 60)), ("dense", problems.random_qp(12, 2400, 3000, 0.01, 50))]
+    for lin, p in cases:
+        monkeypatch.setenv("QPDO_LINSOLVE", lin)
+        monkeypatch.setenv("QPDO_CTRL_PUBLISH", "0")
+        r0 = solver.solve_problem(p, verbose=0)
+        monkeypatch.delenv("QPDO_CTRL_PUBLISH")
+        r1 = solver.solve_problem(p, verbose=0)
+        assert r0["info"]["status_val"] == r1["info"]["status_val"] and r0["info"]["iterations"] == r1["info"]["iterations"], lin
+        assert np.array_equal(r0["x"], r1["x"]) and np.array_equal(r0["y"], r1["y"]), lin
+        assert [(t["kind"], t["n_active"], t["tau"] if t["tau"] == t["tau"] else None) for t in r0["trace"]] == \
+               [(t["kind"], t["n_active"], t["tau"] if t["tau"] == t["tau"] else None) for t in r1["trace"]], lin
+
+
 def test_dense_lowrank_update_matches_refactoring(gpu_required, monkeypatch):
     """few rows entering/leaving: the kept factor is updated instead of rebuilt (reference
     src/cholmod_interface.c:57-93, src/newton.c:21-30); the solve must be indistinguishable from refactoring"""
