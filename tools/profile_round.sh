@@ -7,11 +7,12 @@
 #  2. rocprofv3 --kernel-trace --stats over the same command: per-kernel time of the C4 solve.
 #  3. the driver's default command (python3 bench.py), whole line with its extras.
 set -e
-TAG=${1:-r04}; COMMIT=${2:-unknown}
+TAG=${1:-r04}; COMMIT=${2:-unknown}; STAGE=${3:-all}      # stage: all | c4 (steps 1-2) | rest (step 4 + the default bench line): two gpurun calls
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 ARGS="bench.py --no-cpu-baseline --no-other-configs --no-mixed-extra"
+if [ "$STAGE" != "rest" ]; then
 python3 $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 echo "plain run done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
@@ -29,6 +30,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o c4 -- python3
 cp $(find $OUT/kt -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_c4_bench_kernel_stats.csv
 rm -rf $OUT/kt
 echo "kernel stats done"
+fi
+if [ "$STAGE" = "c4" ]; then exit 0; fi
 #  4. (round 5) the other configurations the bench line quotes, on the same build: MFMA-busy counters of the dense factorization kernel at
 #     C2 (one --pmc pass, no trace domain; installed in profiles/ BEFORE the default bench run, which cites it), rocprofv3 kernel statistics
 #     of the C2 solve and of the C3 batch kernel, kernel timelines of one C1 and one n = 1000 solve.
