@@ -18,6 +18,11 @@
  *   QPDO_DENSE_MID   "0": the dense factorization as the multi-launch blocked pipeline of rounds 1-4 instead of ONE launch of tile-owning
  *                    workgroups (k_mid_factor, the default at every order since round 5: n = 1e4 8.4 ms against 13.3 ms).  The
  *                    look-ahead / outer-panel / syrk knobs below act on the multi-launch path only
+ *   QPDO_CTRL_PUBLISH "0": the per-pass read-back of the control block as hipMemcpyAsync + hipStreamSynchronize instead of a kernel that
+ *                    writes the block and a sequence word into coherent pinned memory while the host spins (bounded; default since round 5:
+ *                    15.7 -> 9.9 us per read-back).  Only the transport differs: the same bits
+ *   QPDO_FUSE_RESID  "0": the deferred Newton step's five axpys and the read-back's publication as launches of their own instead of
+ *                    inside the residual launch (dense / band routes; the same bits)
  *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change, "1": low-rank update of the kept dense factor (default: from n = 9000 up)
  *   QPDO_DENSE_LOOKAHEAD "0": factor on one stream, "1": overlap the next panel with the trailing update (default: from n = 7000 up)
  *   QPDO_DENSE_RESERVE_CUS  CUs left out of the trailing-update stream's mask (default 32; 0 = no mask)
