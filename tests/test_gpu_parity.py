@@ -147,7 +147,7 @@ def test_spmv_matches_oracle(shape, kernel, gpu_required, monkeypatch):
     s.delete()
 
 
-@pytest.mark.parametrize("m", [1, 5, 300, 512, 900, 1500, 2048, 5000, 70000])
+@pytest.mark.parametrize("m", [1, 5, 300, 512, 900, 1500, 2048, 3000, 4096, 5000, 70000])
 def test_linesearch_matches_oracle(m, gpu_required):
     rng = np.random.default_rng(m)
     delta = rng.standard_normal(2 * m); delta[m:] = -delta[:m]
