@@ -320,10 +320,18 @@ def test_control_block_read_back_by_publication_is_the_copy_path_bit_for_bit(gpu
         r0 = solver.solve_problem(p, verbose=0)
         monkeypatch.delenv("QPDO_CTRL_PUBLISH")
         r1 = solver.solve_problem(p, verbose=0)
-        assert r0["info"]["status_val"] == r1["info"]["status_val"] and r0["info"]["iterations"] == r1["info"]["iterations"], lin
-        assert np.array_equal(r0["x"], r1["x"]) and np.array_equal(r0["y"], r1["y"]), lin
-        assert [(t["kind"], t["n_active"], t["tau"] if t["tau"] == t["tau"] else None) for t in r0["trace"]] == \
-               [(t["kind"], t["n_active"], t["tau"] if t["tau"] == t["tau"] else None) for t in r1["trace"]], lin
+        # ... and the launches folded into others this round -- the step's axpys and the publication in the residual launch
+        # (QPDO_FUSE_RESID), the outer-update sequences in 4 + 8 launches instead of 8 + 13 (QPDO_FUSE_OUTER) -- against their separate kernels
+        monkeypatch.setenv("QPDO_FUSE_RESID", "0")
+        monkeypatch.setenv("QPDO_FUSE_OUTER", "0")
+        r2 = solver.solve_problem(p, verbose=0)
+        monkeypatch.delenv("QPDO_FUSE_RESID")
+        monkeypatch.delenv("QPDO_FUSE_OUTER")
+        for r in (r1, r2):
+            assert r0["info"]["status_val"] == r["info"]["status_val"] and r0["info"]["iterations"] == r["info"]["iterations"], lin
+            assert np.array_equal(r0["x"], r["x"]) and np.array_equal(r0["y"], r["y"]), lin
+            assert [(t["kind"], t["n_active"], t["tau"] if t["tau"] == t["tau"] else None) for t in r0["trace"]] == \
+                   [(t["kind"], t["n_active"], t["tau"] if t["tau"] == t["tau"] else None) for t in r["trace"]], lin
 
 
 def test_dense_lowrank_update_matches_refactoring(gpu_required, monkeypatch):
