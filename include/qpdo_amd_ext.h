@@ -23,6 +23,8 @@
  *                    15.7 -> 9.9 us per read-back).  Only the transport differs: the same bits
  *   QPDO_FUSE_RESID  "0": the deferred Newton step's five axpys and the read-back's publication as launches of their own instead of
  *                    inside the residual launch (dense / band routes; the same bits)
+ *   QPDO_LS_SMALL    "0": the linesearch through the radix-sort kernels (28 launches) at every size instead of ONE launch for 2m <= 8192
+ *                    (read at qpdo_setup; the same tau bits: tests/test_gpu_parity.py)
  *   QPDO_FUSE_OUTER  "0": the outer-update sequences (infeasibility tests, mu update, shifting the estimates) as their separate kernels and
  *                    device copies (27 launches) instead of 15 (the same bits)
  *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change, "1": low-rank update of the kept dense factor (default: from n = 9000 up)

@@ -171,6 +171,38 @@ def test_linesearch_matches_oracle(m, gpu_required):
     s.delete()
 
 
+@pytest.mark.parametrize("m", [100, 600, 1100, 2048, 3000, 4096])
+def test_one_launch_linesearch_is_the_radix_path_bit_for_bit(m, gpu_required, monkeypatch):
+    """k_ls_small (2m <= 8192: compaction, register bitonic network or side-by-side chunks + rank merge, the scans of the multi-launch
+    kernels in their order) against the radix-sort path (QPDO_LS_SMALL=0) on candidates full of EXACT ties -- ratios from a handful of
+    values, so that equal keys straddle every chunk boundary and only the index tie-break orders them -- and on generic ones: the same tau
+    bits, and the oracle's value."""
+    p = problems.random_qp(1, 4, m, 0.5)
+    for variant in ("ties", "generic", "all_positive"):
+        rng = np.random.default_rng(7 * m + len(variant))
+        if variant == "ties":
+            delta = rng.choice([-2.0, -1.0, -0.5, 0.5, 1.0, 2.0], 2 * m)
+            alpha = delta * rng.choice([0.25, 0.5, 1.0, 3.0, -1.0], 2 * m)       # t = alpha / delta takes five values
+        elif variant == "generic":
+            delta = rng.standard_normal(2 * m); alpha = rng.standard_normal(2 * m)
+        else:
+            delta = np.abs(rng.standard_normal(2 * m)) + 0.1; alpha = delta * (0.01 + rng.random(2 * m))   # every candidate is a breakpoint
+        eta = 0.9 + rng.random()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            act0 = ((alpha / delta) > 0) != (delta > 0)
+        beta = -abs(float((delta[act0] * alpha[act0]).sum())) - 0.5 - rng.random()
+        ref = ob.pwa_linesearch(eta, beta, delta, alpha)
+        taus = []
+        for small in ("1", "0"):
+            monkeypatch.setenv("QPDO_LS_SMALL", small)
+            s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0, scaling=0)
+            taus.append(s.linesearch(eta, beta, delta, alpha))
+            s.delete()
+        monkeypatch.delenv("QPDO_LS_SMALL")
+        assert taus[0] == taus[1], (m, variant, taus)
+        assert abs(taus[0] - ref) <= 1e-10 * max(1.0, abs(ref)), (m, variant)
+
+
 @pytest.mark.parametrize("size", ["C1", "mid"])
 def test_warm_start_and_update_sequence_matches_oracle(size, linsolve, gpu_required, monkeypatch):
     """qpdo_warm_start / qpdo_update_bounds / qpdo_update_q / qpdo_update_settings followed by re-solves on one
