@@ -26,7 +26,11 @@
  *   QPDO_LS_SMALL    "0": the linesearch through the radix-sort kernels (28 launches) at every size instead of ONE launch for 2m <= 8192
  *                    (read at qpdo_setup; the same tau bits: tests/test_gpu_parity.py)
  *   QPDO_FUSE_OUTER  "0": the outer-update sequences (infeasibility tests, mu update, shifting the estimates) as their separate kernels and
- *                    device copies (27 launches) instead of 15 (the same bits)
+ *                    device copies (27 launches) instead of 15 (the same bits); also: Q dx and A dx of a Newton step as two launches
+ *   QPDO_LAUNCH_AHEAD "0": the Newton step of a pass is launched after the host has read the pass's norms and decided, instead of behind
+ *                    the residual launch with the decision formed on the device (mid-size dense route, n < 9000, 2m <= 8192; DESIGN.md
+ *                    section 5; read at qpdo_setup; QPDOAmdStats.ahead_steps / ahead_skips).  The same kernels in the same order: the same bits,
+ *                    except on a pass whose factor the host-first path would keep (it is refactored: the same matrix)
  *   QPDO_DENSE_LOWRANK  "0": refactor on every weight change, "1": low-rank update of the kept dense factor (default: from n = 9000 up)
  *   QPDO_DENSE_LOOKAHEAD "0": factor on one stream, "1": overlap the next panel with the trailing update (default: from n = 7000 up)
  *   QPDO_DENSE_RESERVE_CUS  CUs left out of the trailing-update stream's mask (default 32; 0 = no mask)
@@ -112,6 +116,8 @@ typedef struct {
                              * `linsolve` reads 1 for such a workspace although its first passes ran PCG                                    */
     long   band_fallbacks;  /* band factorizations that met a non-positive or non-finite pivot and were redone by the dense solver / PCG   */
     long   onelaunch_factors;/* dense factorizations that ran as ONE launch of the tile-dataflow kernel (k_mid_factor, the default)          */
+    long   ahead_steps;     /* Newton steps launched ahead of the host's decision (mid-size dense route, QPDO_LAUNCH_AHEAD) that ran ...   */
+    long   ahead_skips;     /* ... and passes whose launched-ahead step left at once because the pass was an outer update or the last one  */
 } QPDOAmdStats;
 
 int  qpdo_amd_device_count(void);

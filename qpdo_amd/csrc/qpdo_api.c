@@ -711,6 +711,7 @@ void qpdo_solve(QPDOWorkspace *work) {
     qdev_reset_stats(dev);
     c_int iter = 0, oter = 0, iter_old = 0;
     long tr_pending = -1;           /* index of the trace record whose tau is still in flight (deferred step read-back) */
+    c_int last_nchange = -1;        /* n_enter + n_leave of the last Newton pass (-1: none yet / an outer update came after it) */
     if (!work->initialized) goto done;      /* warm start failed on the device */
     if (be->small && !s->verbose) { fused_solve(work); return; }
     if (!be->ws_state) {                    /* (cannot happen: the automatic cold start is skipped only when this solve takes the fused path) */
@@ -727,7 +728,17 @@ void qpdo_solve(QPDOWorkspace *work) {
 
     for (iter = 0; iter < s->max_iter; iter++) {
         QdevResid r;
-        DEVCALL(qdev_residuals(dev, prox, work->sigma, &r));
+        /* launch-ahead (qpdo_dev.h qdev_residuals_ahead): on the mid-size dense route this pass's Newton step is enqueued behind the
+         * residual launch, which forms the decisions below on the device from what the host knows now; the host still makes them itself
+         * from the norms it reads back, and any disagreement ends the solve with QPDO_ERROR */
+        QdevAhead ah;
+        ah.allow_outer = iter > iter_old + 1; ah.force_outer = (iter == iter_old + s->inner_max_iter);
+        ah.reset_newton = be->reset_newton || (s->reset_newton_iter > 0 && (iter % s->reset_newton_iter == 0));
+        ah.max_rank = QPDO_MAX_RANK_UPDATE; ah.eps_abs = s->eps_abs; ah.eps_in = work->eps_in; ah.infty = QPDO_INFTY;
+        /* (not when the last Newton pass saw no row enter or leave and nothing forces a new factorization: the active set tends to
+         * stand still then, the host-first path keeps its factor on such a pass and the launched-ahead step would refactor) */
+        const int ahead_ok = !s->verbose && (ah.reset_newton || last_nchange != 0);
+        DEVCALL(qdev_residuals_ahead(dev, prox, work->sigma, ahead_ok ? &ah : NULL, &r));
         if (r.prev_step_done) {
             work->tau = r.prev_tau;
             if (tr_pending >= 0 && tr_pending < be->ntrace) be->trace[tr_pending].tau = r.prev_tau;
@@ -745,11 +756,18 @@ void qpdo_solve(QPDOWorkspace *work) {
             print_iteration(iter, work);
         }
         /* check_outer_optimality (termination.c:11-23) */
-        if ((r.res_prim > QPDO_INFTY) || (r.res_dual > QPDO_INFTY)) { update_status(work->info, QPDO_NON_CVX); break; }
-        if ((r.res_prim <= s->eps_abs) && (r.res_dual <= s->eps_abs)) { update_status(work->info, QPDO_SOLVED); break; }
+        const int ends_nc = (r.res_prim > QPDO_INFTY) || (r.res_dual > QPDO_INFTY);
+        const int ends_ok = !ends_nc && (r.res_prim <= s->eps_abs) && (r.res_dual <= s->eps_abs);
         const int inner_opt = (r.res_prim_in <= work->eps_in) && (r.res_dual_in <= work->eps_in);   /* termination.c:28-30 */
+        const int outer_pass = ((iter > iter_old + 1) && inner_opt) || (iter == iter_old + s->inner_max_iter);
+        if (r.ahead_went && (ends_nc || ends_ok || outer_pass)) {
+            QPDO_EPRINT("launch-ahead: the device started a Newton step in pass %ld, which the host ends or makes an outer update", (long)iter);
+            update_status(work->info, QPDO_ERROR); break;
+        }
+        if (ends_nc) { update_status(work->info, QPDO_NON_CVX); break; }
+        if (ends_ok) { update_status(work->info, QPDO_SOLVED); break; }
 
-        if (((iter > iter_old + 1) && inner_opt) || (iter == iter_old + s->inner_max_iter)) {
+        if (outer_pass) {
             if (tr) tr->kind = 1;
             if (iter < iter_old + s->inner_max_iter) {
                 if (s->eps_prim_inf > 0) {
@@ -793,6 +811,7 @@ void qpdo_solve(QPDOWorkspace *work) {
             DEVCALL(qdev_save_res_prim(dev));
             oter++;
             iter_old = iter;
+            last_nchange = -1;
         } else {
             if (tr) tr->kind = 0;
             /* the reference computes iter % reset_newton_iter, a division by zero for the (valid) setting 0;
@@ -806,6 +825,7 @@ void qpdo_solve(QPDOWorkspace *work) {
             int lin = 0;
             DEVCALL(qdev_newton_step(dev, branch, r.n_enter + r.n_leave, prox, work->sigma, &work->tau, &lin));
             be->newton_passes++;
+            last_nchange = r.n_enter + r.n_leave;
             if (tr && work->tau != work->tau) tr_pending = be->ntrace - 1;        /* NaN: the step's read-back is deferred */
             if (tr) { tr->tau = work->tau; tr->n_active = r.n_active; tr->n_enter = r.n_enter; tr->n_leave = r.n_leave; tr->factor_branch = branch; tr->lin_iters = lin; }
         }
@@ -982,6 +1002,7 @@ int qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out) {
     out->pcg_rescues = (long)st.pcg_rescues; out->pcg_rescue_kinds = (long)st.pcg_rescue_kinds;
     out->hybrid_pcg_passes = (long)st.hybrid_pcg_passes; out->band_fallbacks = (long)st.band_fallbacks;
     out->onelaunch_factors = (long)st.onelaunch_factors;
+    out->ahead_steps = (long)st.ahead_steps; out->ahead_skips = (long)st.ahead_skips;
     out->fused_solves = work->chol->fused_solves;
     out->fused_kernel_s = work->chol->last_fused ? work->chol->fused_kernel_s : 0.0;
     if (work->chol->last_fused) { out->factor_count = work->chol->fused_factor_count; out->linsolve = 2; }

@@ -34,7 +34,18 @@ typedef struct {
     int32_t n_active, n_enter, n_leave;
     /* a Newton step whose read-back was deferred (qdev_set_deferred_step) completes with the NEXT residual pass: its step length */
     int32_t prev_step_done; double prev_tau;
+    /* launch-ahead (qdev_residuals_ahead): 1 = a Newton step was enqueued behind this residual pass; went = the device let it run, with
+     * factorization branch `ahead_branch` -- the caller's own decision must agree (qdev_newton_step checks) */
+    int32_t ahead_enqueued, ahead_went, ahead_branch;
 } QdevResid;
+/* what the device needs to form the caller's decision for this pass (qpdo_api.c qpdo_solve) */
+typedef struct {
+    int32_t allow_outer;        /* iter > iter_old + 1                          */
+    int32_t force_outer;        /* iter == iter_old + inner_max_iter            */
+    int32_t reset_newton;       /* the flag as the inner branch would see it (including the periodic reset of this iter) */
+    int32_t max_rank;           /* QPDO_MAX_RANK_UPDATE (newton.c:23)           */
+    double eps_abs, eps_in, infty /* QPDO_INFTY */;
+} QdevAhead;
 
 /* per-solve device statistics (extension; see include/qpdo_amd_ext.h) */
 typedef struct {
@@ -59,6 +70,8 @@ typedef struct {
     int64_t hybrid_pcg_passes;  /* hybrid PCG -> dense: Newton passes that were solved by PCG before the dense factor took over */
     int64_t band_fallbacks;     /* band factorizations that met a non-positive / non-finite pivot and were redone by another solver */
     int64_t onelaunch_factors;  /* dense factorizations through the one-launch tile-dataflow kernel (k_mid_factor) */
+    int64_t ahead_steps;        /* Newton steps that were enqueued behind their pass's residual launch and went ahead on the device's own decision */
+    int64_t ahead_skips;        /* passes whose launched-ahead step left at once (outer update, termination, lost producer) */
 } QdevStats;
 
 int qdev_device_count(void);
@@ -118,6 +131,11 @@ int qdev_begin_solve(QpdoDev *d);
 /* outer + inner residuals, norms, active-set counts (iteration.c:30-93, termination.c:35-77,
  * newton.c:96-126) */
 int qdev_residuals(QpdoDev *d, int proximal, double sigma, QdevResid *out);
+/* The same, with this pass's Newton step launched AHEAD of the host's decision (mid-size dense workspaces: the device idles ~20 us per
+ * pass while the host reads the norms and launches the step's first kernels): the residual launch forms the decision itself
+ * (vector.inc SpecArgs), the step's kernels are enqueued behind it guarded by that decision, and the host reads the control block
+ * while they run.  Falls back to qdev_residuals when the workspace is not on that route (ahead == NULL, or see spec_route_ok). */
+int qdev_residuals_ahead(QpdoDev *d, int proximal, double sigma, const QdevAhead *ahead, QdevResid *out);
 
 /* one Newton step (iteration.c:11-25): factor-state update, direction, exact linesearch,
  * iterate update.  branch: 0 full (d = active/mu), 1 rank update (enter/leave), 2 Q only. */

@@ -96,7 +96,7 @@ class Stats(C.Structure):
                 ("inner_steps", C.c_long), ("inner_collectives", C.c_long), ("chain_fallbacks", C.c_long),
                 ("pcg_max_relres", C.c_double), ("pcg_dense_fallbacks", C.c_long), ("fused_solves", C.c_long), ("fused_kernel_s", C.c_double),
                 ("pcg_rescues", C.c_long), ("pcg_rescue_kinds", C.c_long), ("hybrid_pcg_passes", C.c_long), ("band_fallbacks", C.c_long),
-                ("onelaunch_factors", C.c_long)]
+                ("onelaunch_factors", C.c_long), ("ahead_steps", C.c_long), ("ahead_skips", C.c_long)]
 
 
 API_SYMBOLS = ["qpdo_set_default_settings", "qpdo_setup", "qpdo_warm_start", "qpdo_solve", "qpdo_update_settings",

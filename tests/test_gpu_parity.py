@@ -366,6 +366,86 @@ def test_control_block_read_back_by_publication_is_the_copy_path_bit_for_bit(gpu
                    [(t["kind"], t["n_active"], t["tau"] if t["tau"] == t["tau"] else None) for t in r["trace"]], lin
 
 
+def test_newton_step_launched_ahead_of_the_host_decision_changes_no_bit(gpu_required, monkeypatch):
+    """Mid-size dense route: the Newton step of a pass is enqueued behind the residual launch, which forms the host's decision (end of the
+    solve / outer update / factorization branch: qpdo.c:343-449, newton.c:21-33) on the device; the step's kernels leave at once when the
+    answer is no (dev/host_step.inc ahead_enqueue_step, QPDO_LAUNCH_AHEAD=0: the host decides first).  The kernels and their order are the
+    same, so every count, every per-pass record and every bit of the iterates must be: cold solves with and without Ruiz scaling, without
+    the proximal term, with inner_max_iter forcing outer updates, a primal-infeasible instance (the solve ends in an outer update), and a
+    warm start / update sequence on one workspace.  The statistics must show that the steps did go ahead."""
+    def rec(t):
+        return (t["kind"], t["n_active"], t["n_enter"], t["n_leave"], t["factor_branch"], t["tau"] if t["tau"] == t["tau"] else None,
+                t["res_prim"], t["res_dual"], t["res_prim_in"], t["res_dual_in"], t["sigma"], t["eps_in"])
+    def same(a, b, what):
+        assert (a["info"]["status_val"], a["info"]["iterations"], a["info"]["oterations"]) == \
+               (b["info"]["status_val"], b["info"]["iterations"], b["info"]["oterations"]), what
+        for k in ("x", "y", "prim_inf_cert"):          # (NaN where the status does not define them)
+            assert np.array_equal(a[k], b[k], equal_nan=True), (what, k)
+        assert [rec(t) for t in a["trace"]] == [rec(t) for t in b["trace"]], what
+    pinf = problems.random_qp(62, 300, 420, 0.05)
+    A = pinf["A"].tolil(); A[1, :] = A[0, :]; pinf["A"] = A.tocsc()
+    pinf["l"][0], pinf["u"][0], pinf["l"][1], pinf["u"][1] = 1.0, 2.0, -2.0, -1.0
+    cases = [("C1", problems.config_qp("C1"), {}), ("n300", problems.random_qp(31, 300, 600, 0.1), {}),
+             ("unscaled", problems.random_qp(8, 260, 300, 0.05, 20), dict(scaling=0)), ("no proximal term", problems.random_qp(9, 220, 500, 0.05), dict(proximal=0)),
+             ("inner_max_iter 3", problems.random_qp(10, 400, 700, 0.03), dict(inner_max_iter=3, max_iter=400)),
+             ("reset_newton_iter 4", problems.random_qp(13, 330, 500, 0.04), dict(reset_newton_iter=4)),
+             ("primal infeasible", pinf, dict(max_iter=500))]
+    went = n_kept = 0
+    for what, p, kw in cases:
+        monkeypatch.setenv("QPDO_LAUNCH_AHEAD", "0")
+        r0 = solver.solve_problem(p, verbose=0, **kw)
+        monkeypatch.delenv("QPDO_LAUNCH_AHEAD")
+        r1 = solver.solve_problem(p, verbose=0, **kw)
+        assert r0["stats"]["ahead_steps"] == 0 and r0["stats"]["ahead_skips"] == 0 and r0["stats"]["linsolve"] == 1, what
+        # A pass whose factor the host-first path keeps (branch 1 with nothing entered or left, or two Q-only passes in a row) is
+        # refactored by the launched-ahead step: the same matrix, but the forward solve then rides on the factorization launch instead of
+        # the chained kernel -- on instances with such a pass the last bits may differ, so they are compared like two solvers.
+        kept = r0["stats"]["factor_count"] < r0["stats"]["newton_passes"]
+        assert r0["stats"]["factor_count"] <= r1["stats"]["factor_count"] <= r1["stats"]["newton_passes"], what
+        if not kept:
+            same(r1, r0, what)
+        else:
+            n_kept += 1
+            assert_same_outcome(r1, r0["info"], r0["x"], r0["y"], p)
+            assert [rec(t)[:5] for t in r1["trace"]] == [rec(t)[:5] for t in r0["trace"]], what
+        st = r1["stats"]
+        # every Newton step after the first (which allocates the dense factor) goes ahead, except the steps that follow a Newton pass in
+        # which no row entered or left (the host-first path may keep its factor there, so the host decides first: qpdo_api.c ahead_ok);
+        # every other pass that tried was an outer update or the last one
+        tr = r1["trace"]
+        quiet = sum(1 for i in range(1, len(tr)) if tr[i - 1]["kind"] == 0 and tr[i - 1]["n_enter"] + tr[i - 1]["n_leave"] == 0)
+        assert st["newton_passes"] - 1 - quiet <= st["ahead_steps"] <= st["newton_passes"] - 1 and st["chain_fallbacks"] == 0, (what, st, quiet)
+        tried = r1["info"]["iterations"] - 1 + (1 if r1["info"]["status_val"] in (1, -3, -4) else 0)
+        assert tried - quiet <= st["ahead_steps"] + st["ahead_skips"] <= tried, (what, st, quiet)
+        went += st["ahead_steps"]
+    assert went > 100 and n_kept <= 2
+    # one workspace, several solves: the dense factor exists from the second solve's first pass on
+    p = problems.random_qp(71, 500, 900, 0.03, 40)
+    outs = []
+    for ahead in ("0", "1"):
+        monkeypatch.setenv("QPDO_LAUNCH_AHEAD", ahead)
+        s = solver.QPDO().setup(p["Q"], p["q"], p["A"], p["l"], p["u"], Qstype=-1, verbose=0)
+        rs = [s.solve()]
+        rng = np.random.default_rng(0)
+        s.warm_start(rs[0]["x"] + 1e-3 * rng.standard_normal(p["n"]), rs[0]["y"] + 1e-3 * rng.standard_normal(p["m"]))
+        rs.append(s.solve())
+        s.update_bounds(p["l"] - 0.1, p["u"] + 0.05)
+        rs.append(s.solve())
+        s.update_q(1.5 * p["q"] + 0.1)
+        rs.append(s.solve())
+        s.update_settings(eps_abs=1e-8)
+        rs.append(s.solve())
+        for r in rs:
+            r["trace"] = None
+        outs.append((rs, s.stats()))
+        s.delete()
+    monkeypatch.delenv("QPDO_LAUNCH_AHEAD")
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert (a["info"]["status_val"], a["info"]["iterations"], a["info"]["oterations"]) == (b["info"]["status_val"], b["info"]["iterations"], b["info"]["oterations"])
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["y"], b["y"])
+    assert outs[0][1]["ahead_steps"] == 0 and 0 < outs[1][1]["ahead_steps"] <= outs[1][1]["newton_passes"]
+
+
 def test_dense_lowrank_update_matches_refactoring(gpu_required, monkeypatch):
     """few rows entering/leaving: the kept factor is updated instead of rebuilt (reference
     src/cholmod_interface.c:57-93, src/newton.c:21-30); the solve must be indistinguishable from refactoring"""
