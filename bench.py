@@ -811,7 +811,8 @@ def main():
             c1 = dict(workload="n=200, m=100, density 0.1 (examples/demo_mex.m:7-9), cold start, default settings + max_iter=200", cold_solve_ms=1e3 * best1,
                       iterations=rc1["info"]["iterations"], oterations=rc1["info"]["oterations"], status_val=rc1["info"]["status_val"],
                       newton_iters_per_s=stc1["newton_passes"] / best1, factor_count=stc1["factor_count"], onelaunch_factors=stc1.get("onelaunch_factors"),
-                      route="fused one-launch kernel" if stc1["linsolve"] == 2 else "generic path, dense LDL' in one launch per factorization")
+                      steps_launched_ahead=stc1.get("ahead_steps"), launched_ahead_steps_that_left=stc1.get("ahead_skips"),
+                      route="fused one-launch kernel" if stc1["linsolve"] == 2 else "generic path, dense LDL' in one launch per factorization; Newton steps launched ahead of the host's decision")
             if not a.no_cpu_baseline:
                 c1["cpu_baseline"] = cpu_baseline_small(pc1, host_cores(), 10, max_iter=200)
                 c1["cpu_baseline"]["single_thread"] = cpu_baseline_small(pc1, 1, 10, max_iter=200)
