@@ -843,8 +843,8 @@ done:
     work->info->iterations = iter;
     work->info->oterations = oter;
     /* store_solution (termination.c:82-92) + host mirrors */
-    if (qdev_store_solution(dev, work->solution->x, work->solution->y, work->x, work->y, work->dx, work->dy) ||
-        qdev_objective(dev, prox, work->sigma, work->data->c, &work->info->objective)) {
+    if (qdev_store_solution_obj(dev, prox, work->sigma, work->data->c, work->solution->x, work->solution->y, work->x, work->y, work->dx, work->dy,
+                                &work->info->objective)) {
         QPDO_EPRINT("device backend: %s", qdev_last_error());
         update_status(work->info, QPDO_ERROR);
     }

@@ -159,6 +159,9 @@ int qdev_save_res_prim(QpdoDev *d);                                             
 int qdev_objective(QpdoDev *d, int proximal, double sigma, double c_const, double *objective);
 int qdev_store_solution(QpdoDev *d, double *sol_x, double *sol_y, double *x, double *y,
                         double *dx, double *dy);
+/* both at the end of qpdo_solve: one device-to-host copy (pinned) and one synchronisation instead of six copies + two */
+int qdev_store_solution_obj(QpdoDev *d, int proximal, double sigma, double c_const, double *sol_x, double *sol_y, double *x, double *y,
+                            double *dx, double *dy, double *objective);
 /* qdpo_update_q support (qpdo.c:549-586): Qx -= sigma x ; returns ||q + cinv Qx||inf etc. on host */
 int qdev_download_vec(QpdoDev *d, int which, double *dst);   /* 0 x, 1 Qx, 2 y */
 int qdev_upload_vec(QpdoDev *d, int which, const double *src);
