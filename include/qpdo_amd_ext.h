@@ -26,7 +26,7 @@
  *   QPDO_LS_SMALL    "0": the linesearch through the radix-sort kernels (28 launches) at every size instead of ONE launch for 2m <= 8192
  *                    (read at qpdo_setup; the same tau bits: tests/test_gpu_parity.py)
  *   QPDO_FUSE_OUTER  "0": the outer-update sequences (infeasibility tests, mu update, shifting the estimates) as their separate kernels and
- *                    device copies (27 launches) instead of 15 (the same bits); also: Q dx and A dx of a Newton step as two launches
+ *                    device copies (27 launches) instead of 10 (the same bits); also: Q dx and A dx of a Newton step as two launches
  *   QPDO_LAUNCH_AHEAD "0": the Newton step of a pass is launched after the host has read the pass's norms and decided, instead of behind
  *                    the residual launch with the decision formed on the device (mid-size dense route, n < 9000, 2m <= 8192; DESIGN.md
  *                    section 5; read at qpdo_setup; QPDOAmdStats.ahead_steps / ahead_skips).  The same kernels in the same order: the same bits,
