@@ -121,6 +121,13 @@ typedef struct {
 } QPDOAmdStats;
 
 int  qpdo_amd_device_count(void);
+/* What a loop pass of qpdo_solve is, from its residual norms and active-set counts (reference src/termination.c:11-30, src/qpdo.c:361-363,
+ * src/newton.c:21-33): the one function behind both the host loop and the residual launch's decision on the launch-ahead route
+ * (qpdo_amd/csrc/pass_decision.h).  Pure host arithmetic (no device needed): exported for the CPU tests.  res_dual / res_dual_in: already
+ * multiplied by cinv.  allow_outer: iter > iter_old + 1; force_outer: iter == iter_old + inner_max_iter; n_change: n_enter + n_leave.
+ * Out: the solve ends with QPDO_NON_CVX / QPDO_SOLVED, the pass is an outer update, else a Newton step with factorization branch 0 | 1 | 2. */
+int  qpdo_amd_pass_decision(double res_prim, double res_dual, double res_prim_in, double res_dual_in, double eps_abs, double eps_in, int allow_outer,
+                            int force_outer, int reset_newton, int n_active, int n_change, int *ends_nc, int *ends_ok, int *outer, int *branch);
 const char *qpdo_amd_last_error(void);
 int  qpdo_amd_get_stats(const QPDOWorkspace *work, QPDOAmdStats *out);
 /* trace of the last qpdo_solve; pointer stays valid until the next solve / cleanup */

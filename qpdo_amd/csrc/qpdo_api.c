@@ -21,6 +21,7 @@
 #include "qpdo.h"
 #include "qpdo_amd_ext.h"
 #include "qpdo_dev.h"
+#include "pass_decision.h"
 
 struct QPDO_TIMER { struct timespec tic, toc; };   /* reference include/util.h:98-104 */
 
@@ -756,10 +757,12 @@ void qpdo_solve(QPDOWorkspace *work) {
             print_iteration(iter, work);
         }
         /* check_outer_optimality (termination.c:11-23) */
-        const int ends_nc = (r.res_prim > QPDO_INFTY) || (r.res_dual > QPDO_INFTY);
-        const int ends_ok = !ends_nc && (r.res_prim <= s->eps_abs) && (r.res_dual <= s->eps_abs);
-        const int inner_opt = (r.res_prim_in <= work->eps_in) && (r.res_dual_in <= work->eps_in);   /* termination.c:28-30 */
-        const int outer_pass = ((iter > iter_old + 1) && inner_opt) || (iter == iter_old + s->inner_max_iter);
+        /* (pass_decision.h: termination.c:11-30, qpdo.c:361-363, newton.c:21-33 -- the function the residual launch itself evaluates on the
+         * launch-ahead route, on the same numbers) */
+        const QpdoPassDecision pd = qpdo_pass_decision(r.res_prim, r.res_dual, r.res_prim_in, r.res_dual_in, s->eps_abs, work->eps_in, QPDO_INFTY,
+                                                       ah.allow_outer, ah.force_outer, ah.reset_newton, (int)r.n_active, (int)(r.n_enter + r.n_leave),
+                                                       QPDO_MAX_RANK_UPDATE);
+        const int ends_nc = pd.ends_nc, ends_ok = pd.ends_ok, outer_pass = pd.outer;
         if (r.ahead_went && (ends_nc || ends_ok || outer_pass)) {
             QPDO_EPRINT("launch-ahead: the device started a Newton step in pass %ld, which the host ends or makes an outer update", (long)iter);
             update_status(work->info, QPDO_ERROR); break;
@@ -818,10 +821,8 @@ void qpdo_solve(QPDOWorkspace *work) {
              * here 0 means "no periodic refactorization" */
             if (s->reset_newton_iter > 0 && (iter % s->reset_newton_iter == 0)) be->reset_newton = 1;
             /* factorization decision (newton.c:21-33) */
-            int branch;
-            if ((be->reset_newton && r.n_active) || (r.n_enter + r.n_leave) > QPDO_MAX_RANK_UPDATE) { be->reset_newton = 0; branch = 0; }
-            else if (r.n_active) branch = 1;
-            else branch = 2;
+            const int branch = pd.branch;          /* (ah.reset_newton is be->reset_newton after the line above) */
+            if (branch == 0) be->reset_newton = 0;
             int lin = 0;
             DEVCALL(qdev_newton_step(dev, branch, r.n_enter + r.n_leave, prox, work->sigma, &work->tau, &lin));
             be->newton_passes++;
@@ -958,6 +959,13 @@ void qpdo_cleanup(QPDOWorkspace *work) {
 
 /* ---- extensions (include/qpdo_amd_ext.h) --------------------------------------------------------------- */
 int qpdo_amd_device_count(void) { return qdev_device_count(); }
+int qpdo_amd_pass_decision(double res_prim, double res_dual, double res_prim_in, double res_dual_in, double eps_abs, double eps_in, int allow_outer,
+                           int force_outer, int reset_newton, int n_active, int n_change, int *ends_nc, int *ends_ok, int *outer, int *branch) {
+    const QpdoPassDecision pd = qpdo_pass_decision(res_prim, res_dual, res_prim_in, res_dual_in, eps_abs, eps_in, QPDO_INFTY, allow_outer, force_outer,
+                                                   reset_newton, n_active, n_change, QPDO_MAX_RANK_UPDATE);
+    *ends_nc = pd.ends_nc; *ends_ok = pd.ends_ok; *outer = pd.outer; *branch = pd.branch;
+    return 0;
+}
 const char *qpdo_amd_last_error(void) { return qdev_last_error(); }
 int qpdo_amd_sync(QPDOWorkspace *work) { return qdev_sync(work->chol->dev); }
 int qpdo_amd_get_trace(const QPDOWorkspace *work, const QPDOAmdTraceRec **recs, long *count) {

@@ -24,6 +24,7 @@
 #include <rccl/rccl.h>
 
 #include "qpdo_dev.h"
+#include "pass_decision.h"
 
 typedef unsigned long long u64;
 typedef unsigned int u32;

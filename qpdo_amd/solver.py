@@ -107,7 +107,7 @@ class BatchItem(C.Structure):
 
 EXT_SYMBOLS = ["qpdo_amd_dist_config", "qpdo_amd_dist_unique_id", "qpdo_amd_solve_batch", "qpdo_amd_batch_kernel_seconds", "qpdo_amd_batch_stream_create",
                "qpdo_amd_batch_stream_submit", "qpdo_amd_batch_stream_wait", "qpdo_amd_batch_stream_destroy", "qpdo_amd_device_count", "qpdo_amd_last_error", "qpdo_amd_get_stats", "qpdo_amd_get_trace",
-               "qpdo_amd_sync", "qpdo_amd_bench_spmv", "qpdo_amd_bench_dense_factor", "qpdo_amd_spmv", "qpdo_amd_linesearch", "qpdo_amd_download"]
+               "qpdo_amd_sync", "qpdo_amd_pass_decision", "qpdo_amd_bench_spmv", "qpdo_amd_bench_dense_factor", "qpdo_amd_spmv", "qpdo_amd_linesearch", "qpdo_amd_download"]
 
 _lib = None
 

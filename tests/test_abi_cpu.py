@@ -185,3 +185,42 @@ def test_host_driver_under_address_and_ub_sanitizers(tmp_path):
     assert "no-device mode: qpdo_setup returned NULL" in txt, txt[-3000:]
     assert "AddressSanitizer" not in txt and "runtime error" not in txt and "LeakSanitizer" not in txt, txt[-3000:]
     assert txt.count("random instance") == 4
+
+
+def test_pass_decision_follows_the_reference_rules():
+    """qpdo_amd/csrc/pass_decision.h through its exported wrapper: the ONE function behind the host loop's per-pass decision and the residual
+    launch's own (launch-ahead route).  Reference: src/termination.c:11-23 (NON_CVX before SOLVED, strict > QPDO_INFTY, <= eps_abs),
+    :28-30 (inner optimality), src/qpdo.c:361-363 (outer update: inner optimum AND a Newton step since the last one, or inner_max_iter
+    passes), src/newton.c:21-33 (branch 0 / 1 / 2; QPDO_MAX_RANK_UPDATE = 100).  NaN norms compare false everywhere, as in the reference."""
+    L = C.CDLL(_build.ensure_lib())
+    f = L.qpdo_amd_pass_decision
+    f.argtypes = [C.c_double] * 6 + [C.c_int] * 5 + [C.POINTER(C.c_int)] * 4
+
+    def dec(rp, rd, rpi, rdi, eps_abs=1e-6, eps_in=1e-2, allow=1, force=0, reset=0, nact=5, nch=3):
+        o = [C.c_int(-1) for _ in range(4)]
+        assert f(rp, rd, rpi, rdi, eps_abs, eps_in, allow, force, reset, nact, nch, *[C.byref(v) for v in o]) == 0
+        return tuple(v.value for v in o)           # ends_nc, ends_ok, outer, branch
+
+    def ref(rp, rd, rpi, rdi, eps_abs=1e-6, eps_in=1e-2, allow=1, force=0, reset=0, nact=5, nch=3):
+        nc = (rp > 1e20) or (rd > 1e20)
+        ok = (not nc) and rp <= eps_abs and rd <= eps_abs
+        outer = (allow and rpi <= eps_in and rdi <= eps_in) or force
+        branch = 0 if ((reset and nact) or nch > 100) else (1 if nact else 2)
+        return (int(nc), int(ok), int(bool(outer)), branch)
+
+    nan, inf = float("nan"), float("inf")
+    cases = [dict(rp=1.0, rd=1.0, rpi=1.0, rdi=1.0), dict(rp=1e-7, rd=1e-6, rpi=1.0, rdi=1.0), dict(rp=1e-6, rd=1.0000001e-6, rpi=1.0, rdi=1.0),
+             dict(rp=1e21, rd=1e-9, rpi=0.0, rdi=0.0), dict(rp=1e20, rd=1e20, rpi=0.0, rdi=0.0), dict(rp=inf, rd=0.0, rpi=0.0, rdi=0.0),
+             dict(rp=nan, rd=nan, rpi=nan, rdi=nan), dict(rp=nan, rd=1e-9, rpi=1e-3, rdi=1e-3),
+             dict(rp=1.0, rd=1.0, rpi=1e-2, rdi=1e-2), dict(rp=1.0, rd=1.0, rpi=1e-2, rdi=1.0000001e-2), dict(rp=1.0, rd=1.0, rpi=1e-3, rdi=1e-3, allow=0),
+             dict(rp=1.0, rd=1.0, rpi=1.0, rdi=1.0, force=1), dict(rp=1.0, rd=1.0, rpi=1e-3, rdi=1e-3, allow=0, force=1),
+             dict(rp=1.0, rd=1.0, rpi=1.0, rdi=1.0, reset=1), dict(rp=1.0, rd=1.0, rpi=1.0, rdi=1.0, reset=1, nact=0),
+             dict(rp=1.0, rd=1.0, rpi=1.0, rdi=1.0, nact=0, nch=0), dict(rp=1.0, rd=1.0, rpi=1.0, rdi=1.0, nch=100), dict(rp=1.0, rd=1.0, rpi=1.0, rdi=1.0, nch=101),
+             dict(rp=1.0, rd=1.0, rpi=1.0, rdi=1.0, nact=0, nch=101), dict(rp=1e-9, rd=1e-9, rpi=0.0, rdi=0.0, force=1)]
+    for c in cases:
+        assert dec(**c) == ref(**c), c
+    # spot values (not through the mirror above)
+    assert dec(1e21, 0.0, 0.0, 0.0)[:2] == (1, 0)                 # NON_CVX wins over SOLVED
+    assert dec(1e-6, 1e-6, 1.0, 1.0)[:2] == (0, 1)                # <= eps_abs
+    assert dec(nan, nan, nan, nan) == (0, 0, 0, 1)                # a NaN iterate is neither ended nor an outer update: the loop goes on
+    assert dec(1.0, 1.0, 1.0, 1.0, reset=1, nact=0)[3] == 2       # the reset flag alone does not force a factorization of an empty active set
